@@ -1,0 +1,220 @@
+/*
+ * raytracing_amd.h - C ABI of the MI355X (gfx950) sphere ray tracer.
+ *
+ * The reference renderer (JoarGunnarsson/Raytracing) is pure Python and has no
+ * FFI of its own.  Its narrowest stable seams are
+ *     raytrace(scene) -> (HEIGHT, WIDTH, 3) float64      reference raytrace.py:273-279
+ *     get_pixel_color(X, Y, scene) -> (n, 3) float64     reference raytrace.py:6-16
+ * and everything executed under them.  This library replaces that execution:
+ * the caller flattens a scene into the plain structs below (what the
+ * reference reads from its Sphere / Material / light / Camera / Screen
+ * objects), and the entry points run the frame as a level-synchronous
+ * wavefront of HIP kernels.  All pointers are plain host pointers unless a
+ * name says "device"; all functions return 0 on success and a negative
+ * RT_ERR_* code otherwise, with a message available from rt_last_error().
+ *
+ * One RtContext drives one GPU; calls on a context must be serialised by the
+ * caller; different contexts are independent.
+ */
+#ifndef RAYTRACING_AMD_H
+#define RAYTRACING_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_MAX_LIGHTS 8
+#define RT_MAX_SPHERES 65535
+#define RT_MAT_WIDTH 18
+#define RT_NUM_COUNTERS (4 + RT_MAX_LIGHTS)
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)   /* bad argument / unsupported scene            */
+#define RT_ERR_HIP (-2)       /* a HIP runtime call failed                   */
+#define RT_ERR_OVERFLOW (-3)  /* the ray arena was too small for this frame  */
+#define RT_ERR_STATE (-4)     /* calls made in the wrong order               */
+
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_DISK = 1, RT_LIGHT_SPOT = 2 };
+enum { RT_EASE_NONE = 0, RT_EASE_LINEAR = 1, RT_EASE_QUADRATIC = 2, RT_EASE_CUBIC = 3,
+       RT_EASE_EXPONENTIAL = 4 };
+
+/* One light source: the attributes the reference's PointSource / DiskSource /
+ * DirectionalDiskSource read in compute_light_intensity (reference
+ * objects.py:94-235).  x_hat / y_hat are the disk's in-plane frame as the
+ * reference builds it (objects.py:124-130, not normalised); tan_angle and
+ * tan_outer are tan(angle) and tan(angle + fall_off_angle) (objects.py:209-210). */
+typedef struct RtLight {
+    int32_t kind;      /* RT_LIGHT_*                                   */
+    int32_t n_points;  /* disk samples per hit (1 for a point light)   */
+    int32_t easing;    /* RT_EASE_*, spotlights only                   */
+    int32_t reserved;
+    double position[3];
+    double intensity;
+    double diffuse_color[3];
+    double specular_color[3];
+    double radius;
+    double normal[3];
+    double x_hat[3];
+    double y_hat[3];
+    double tan_angle;
+    double tan_outer;
+} RtLight;
+
+/* A flattened scene.  sphere_geom is [n_spheres][4] = centre x, y, z, radius
+ * (reference objects.py:54-58).  sphere_mat is [n_spheres][RT_MAT_WIDTH]:
+ *   0-2 ambient colour, 3-5 diffuse colour * diffuse coefficient,
+ *   6-8 specular colour * specular coefficient, 9 shininess,
+ *   10 reflection coefficient, 11 transparency coefficient, 12 refractive index,
+ *   13 smoothness, 14 attenuation coefficient, 15-17 absorption colour
+ * (reference materials.py:4-29, raytrace.py:243-252).  ambient is
+ * AmbientLight.intensity * color (reference raytrace.py:137-138).  The screen
+ * fields are those read by Screen.index_to_position (reference objects.py:45-51). */
+typedef struct RtScene {
+    int32_t n_spheres;
+    int32_t n_lights;
+    const double *sphere_geom;
+    const double *sphere_mat;
+    const RtLight *lights;
+    double ambient[3];
+    double camera_position[3];
+    double screen_position[3];
+    double screen_x[3];
+    double screen_y[3];
+    double screen_width;
+    double screen_height;
+    double pixels_x;
+    double pixels_y;
+} RtScene;
+
+/* Render settings: the reference's module constants (reference constants.py:2-19). */
+typedef struct RtParams {
+    int32_t width;
+    int32_t height;
+    int32_t max_reflection_depth;
+    int32_t max_refraction_depth;
+    int32_t small_num;
+    int32_t reserved;
+    double epsilon;
+    double air_refractive_index;
+    double background[3];
+} RtParams;
+
+/* Frame counters, valid after rt_trace_geometry (and rt_shade for shadow_rays). */
+typedef struct RtCounters {
+    int64_t pixels;          /* primary rays of this context's pixel set               */
+    int64_t rays;            /* rays handed to the nearest-hit search (local batches in
+                                nodes whose global batch is >= small_num)              */
+    int64_t hits;            /* of those, rays that hit a sphere                       */
+    int64_t arena_rays_used; /* ray slots used, including tile padding                 */
+    int64_t arena_capacity;  /* ray slots allocated                                    */
+    int32_t n_nodes;         /* nodes of the static ray tree                           */
+    int32_t n_levels;        /* bounce levels (longest path + 1)                       */
+    int32_t overflow;        /* non-zero: arena too small, results invalid             */
+    int32_t reserved;
+} RtCounters;
+
+/* Accumulated device time per kernel kind, filled when profiling is on. */
+enum { RT_K_TRACE = 0, RT_K_SCAN = 1, RT_K_LINK = 2, RT_K_SHADE = 3, RT_K_INIT = 4, RT_K_COUNT = 5 };
+typedef struct RtProfile {
+    double ms[RT_K_COUNT];
+    int64_t launches[RT_K_COUNT];
+} RtProfile;
+
+typedef struct RtContext RtContext;
+
+/* Last error message of the calling thread ("" if none). */
+const char *rt_last_error(void);
+
+/* Number of GPUs visible to the HIP runtime (0 when there is none; never fails). */
+int rt_device_count(void);
+
+/* Static shape of the ray tree for the given depth limits: the recursion
+ * pattern of reference raytrace.py:103-133 (branch 0 transmit (a, b-1) when
+ * b != 0; branch 1 total internal reflection (a-1, b-1) when a != 0 and b != 0;
+ * branch 2 reflect (a-1, b) when a != 0), numbered breadth first.  Pure host
+ * code (usable without a GPU).  Pass NULL arrays to query sizes only.
+ * a, b, parent, branch, level: [n_nodes]; child: [n_nodes][3]; level_start:
+ * [n_levels + 1]. */
+int rt_build_tree(int32_t max_reflection_depth, int32_t max_refraction_depth,
+                  int32_t *n_nodes, int32_t *n_levels,
+                  int32_t *a, int32_t *b, int32_t *parent, int32_t *branch, int32_t *child,
+                  int32_t *level, int32_t *level_start);
+
+/* Create a context on GPU `device`.  `stream` is a hipStream_t to launch on
+ * (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a private one. */
+int rt_create(int32_t device, void *stream, RtContext **out);
+void rt_destroy(RtContext *ctx);
+
+/* Upload the scene and render settings (replaces everything the reference
+ * reads from `scene` and from its constants inside raytrace(), reference
+ * raytrace.py:273-279). */
+int rt_set_scene(RtContext *ctx, const RtScene *scene, const RtParams *params);
+
+/* Choose the pixels of the next frame and size the ray arena.
+ * Either a block of whole rows [row0, row0 + n_rows) of the width x height
+ * grid (X = NULL, Y = NULL; pixel order is row-major as in reference
+ * raytrace.py:274-276), or n explicit pixel coordinates X[i], Y[i] (the
+ * get_pixel_color form, reference raytrace.py:6-7).  arena_rays is the number
+ * of ray slots to provide (0 = keep / pick a default of 24 per pixel). */
+int rt_begin_frame(RtContext *ctx, int32_t row0, int32_t n_rows,
+                   const double *X, const double *Y, int64_t n, int64_t arena_rays);
+
+/* Geometry phase (reference raytrace.py:19-133 without the lighting): trace
+ * all bounce levels, leaving per-ray hit records and per-node counts on the
+ * device.  Does not synchronise. */
+int rt_trace_geometry(RtContext *ctx);
+
+/* The same phase one level at a time, for callers that split a frame over
+ * several GPUs: after rt_trace_level(l) the local batch sizes of level l+1 are
+ * final; the caller sums them over all GPUs and hands the global sizes back
+ * with rt_set_global_batches before tracing level l+1, because the
+ * small-batch rule (reference raytrace.py:26-27) looks at whole-image batches. */
+int rt_trace_level(RtContext *ctx, int32_t level);
+int rt_get_level_batches(RtContext *ctx, int32_t level, int64_t *n_local /* [nodes of level] */);
+int rt_set_global_batches(RtContext *ctx, int32_t level, const int64_t *n_global);
+
+/* Per-node results of the geometry phase (synchronises):
+ * batch[k] local rays of node k, hits[k] local hits, beam[k][l] local hits
+ * inside spotlight l's beam.  Arrays may be NULL. */
+int rt_get_node_counts(RtContext *ctx, int64_t *batch, int64_t *hits, int64_t *beam /* [n_nodes][RT_MAX_LIGHTS] */);
+
+/* Disk-light samples (reference objects.py:132-133 draws them from NumPy's
+ * global stream; the caller draws them the same way and uploads them).
+ * rt_set_sample_layout gives, per (node, light), the offset of that block in
+ * this context's sample buffer (-1: none) - layout inside a block:
+ * u[s * h + j] is the angle uniform and u[N * h + s * h + j] the radius
+ * uniform of sample s for the j-th (in-beam) hit of the node, h = this
+ * context's (in-beam) hit count, N = n_points - and the total length. */
+int rt_set_sample_layout(RtContext *ctx, const int64_t *offsets /* [n_nodes][RT_MAX_LIGHTS] */, int64_t total);
+int rt_upload_samples(RtContext *ctx, int64_t dst_offset, const double *u, int64_t n);
+
+/* Lighting, shading and bottom-up colour combination (reference
+ * raytrace.py:135-170 and objects.py:94-235), deepest level first.  Leaves the
+ * clipped pixel colours (reference raytrace.py:15) on the device.  Does not
+ * synchronise. */
+int rt_shade(RtContext *ctx);
+
+/* Copy the frame's colours, [n_pixels][3] float64 in pixel order (synchronises). */
+int rt_read_image(RtContext *ctx, double *out_rgb);
+/* Device address of the same buffer (valid until the next rt_begin_frame). */
+int rt_image_device_ptr(RtContext *ctx, void **out);
+
+/* Wait for all work queued by this context. */
+int rt_synchronize(RtContext *ctx);
+
+int rt_get_counters(RtContext *ctx, RtCounters *out);
+
+/* Per-kernel device timing with HIP events on the context's stream. */
+int rt_profile_enable(RtContext *ctx, int32_t on);
+int rt_get_profile(RtContext *ctx, RtProfile *out, int32_t reset);
+
+/* Convenience: rt_begin_frame(whole image) + geometry + shade + read, for
+ * scenes without disk lights (no samples needed). */
+int rt_render(RtContext *ctx, double *out_rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACING_AMD_H */

@@ -1,0 +1,597 @@
+// Host side of the C ABI declared in include/raytracing_amd.h: context, memory,
+// launch sequence.  The kernels are compiled into the same translation unit.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_kernels.hip"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct HostTree {
+    std::vector<int32_t> a, b, parent, branch, child, level, level_start;
+    int n_nodes() const { return (int)a.size(); }
+    int n_levels() const { return (int)level_start.size() - 1; }
+};
+
+// Breadth-first enumeration of the recursion pattern of reference raytrace.py:103-133.
+int build_tree(int refl, int refr, HostTree& t) {
+    if (refl < 0 || refr < 0) return fail(RT_ERR_INVALID, "depth limits must be non-negative");
+    t = HostTree();
+    t.a.push_back(refl); t.b.push_back(refr); t.parent.push_back(-1); t.branch.push_back(-1);
+    t.level.push_back(0); t.child.insert(t.child.end(), {-1, -1, -1});
+    t.level_start.push_back(0);
+    size_t begin = 0, end = 1;
+    while (begin < end) {
+        t.level_start.push_back((int32_t)end);
+        for (size_t node = begin; node < end; ++node) {
+            const int na = t.a[node], nb = t.b[node];
+            const bool allowed[3] = {nb != 0, na != 0 && nb != 0, na != 0};
+            const int ca[3] = {na, na - 1, na - 1}, cb[3] = {nb - 1, nb - 1, nb};
+            for (int c = 0; c < 3; ++c) {
+                if (!allowed[c]) continue;
+                if (t.a.size() >= (size_t)MAX_NODES)
+                    return fail(RT_ERR_INVALID, "ray tree for depths (%d, %d) has more than %d nodes", refl, refr, MAX_NODES);
+                t.child[node * 3 + c] = (int32_t)t.a.size();
+                t.a.push_back(ca[c]); t.b.push_back(cb[c]); t.parent.push_back((int32_t)node);
+                t.branch.push_back(c); t.level.push_back(t.level[node] + 1);
+                t.child.insert(t.child.end(), {-1, -1, -1});
+            }
+        }
+        begin = end;
+        end = t.a.size();
+    }
+    return RT_OK;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct RtContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    bool have_scene = false, frame_begun = false, geometry_done = false, layout_set = false, shaded = false;
+    int next_level = 0;
+    bool sampled_lights = false;
+    SceneConst sc_host{};
+    RtParams params{};
+    HostTree tree;
+    int S = 0;
+
+    DevBuf<double> geom, mat;
+    DevBuf<SceneConst> sc;
+    DevBuf<int32_t> node_a, node_b, node_branch, node_child, level_start;
+    DevBuf<int32_t> node_n, node_nglobal, node_hits, node_beam, node_tile0, node_ntiles, lvl_ntiles, lvl_tilebase, flags;
+    DevBuf<uint32_t> node_start, node_pre, tile_run, blk_tot;
+    DevBuf<double> px, py, pz, dx, dy, dz, nx, ny, nz, A, dist, cr, cg, cb;
+    DevBuf<uint32_t> info, link;
+    DevBuf<double> X, Y, samples, image;
+    DevBuf<int64_t> sample_off;
+
+    int64_t npix = 0;
+    int row0 = 0;
+    bool explicit_xy = false;
+    int64_t arena_rays = 0;
+    int64_t sample_total = 0;
+
+    bool profiling = false;
+    struct Stamp { int kind; hipEvent_t t0, t1; };
+    std::vector<Stamp> stamps;
+    std::vector<hipEvent_t> free_events;
+    RtProfile prof{};
+
+    Dev dev() const {
+        Dev D{};
+        D.geom = geom.p; D.mat = mat.p; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
+        D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
+        D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
+        D.node_n = node_n.p; D.node_nglobal = node_nglobal.p; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
+        D.node_tile0 = node_tile0.p; D.node_ntiles = node_ntiles.p; D.node_start = node_start.p; D.node_pre = node_pre.p;
+        D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p;
+        D.flags = flags.p;
+        D.px = px.p; D.py = py.p; D.pz = pz.p; D.dx = dx.p; D.dy = dy.p; D.dz = dz.p; D.nx = nx.p; D.ny = ny.p; D.nz = nz.p; D.A = A.p; D.dist = dist.p;
+        D.info = info.p; D.link = link.p; D.cr = cr.p; D.cg = cg.p; D.cb = cb.p;
+        D.cap_tiles = (uint32_t)(arena_rays / TILE);
+        D.X = explicit_xy ? X.p : nullptr; D.Y = explicit_xy ? Y.p : nullptr;
+        D.row0 = row0; D.npix = (int32_t)npix;
+        D.samples = samples.p; D.sample_off = sample_off.p;
+        D.image = image.p;
+        return D;
+    }
+
+    hipEvent_t get_event() {
+        if (!free_events.empty()) {
+            hipEvent_t e = free_events.back();
+            free_events.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void begin(int kind) {
+        if (!profiling) return;
+        Stamp s{kind, get_event(), get_event()};
+        (void)hipEventRecord(s.t0, stream);
+        stamps.push_back(s);
+    }
+    void end() {
+        if (!profiling) return;
+        (void)hipEventRecord(stamps.back().t1, stream);
+    }
+    void collect() {
+        for (auto& s : stamps) {
+            float ms = 0;
+            if (hipEventSynchronize(s.t1) == hipSuccess && hipEventElapsedTime(&ms, s.t0, s.t1) == hipSuccess) {
+                prof.ms[s.kind] += ms;
+                prof.launches[s.kind] += 1;
+            }
+            free_events.push_back(s.t0);
+            free_events.push_back(s.t1);
+        }
+        stamps.clear();
+    }
+};
+
+namespace {
+
+int use_device(RtContext* ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+int launch_level(RtContext* ctx, int level) {
+    const Dev D = ctx->dev();
+    ctx->begin(RT_K_TRACE);
+    hipLaunchKernelGGL(k_trace, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
+    ctx->end();
+    ctx->begin(RT_K_SCAN);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, D, level);
+    ctx->end();
+    if (level + 1 < D.n_levels) {
+        ctx->begin(RT_K_LINK);
+        hipLaunchKernelGGL(k_link, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
+        ctx->end();
+    }
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_build_tree(int32_t refl, int32_t refr, int32_t* n_nodes, int32_t* n_levels, int32_t* a, int32_t* b,
+                  int32_t* parent, int32_t* branch, int32_t* child, int32_t* level, int32_t* level_start) {
+    HostTree t;
+    int rc = build_tree(refl, refr, t);
+    if (rc) return rc;
+    if (n_nodes) *n_nodes = t.n_nodes();
+    if (n_levels) *n_levels = t.n_levels();
+    const size_t K = t.a.size();
+    if (a) memcpy(a, t.a.data(), K * 4);
+    if (b) memcpy(b, t.b.data(), K * 4);
+    if (parent) memcpy(parent, t.parent.data(), K * 4);
+    if (branch) memcpy(branch, t.branch.data(), K * 4);
+    if (child) memcpy(child, t.child.data(), K * 12);
+    if (level) memcpy(level, t.level.data(), K * 4);
+    if (level_start) memcpy(level_start, t.level_start.data(), t.level_start.size() * 4);
+    return RT_OK;
+}
+
+int rt_create(int32_t device, void* stream, RtContext** out) {
+    if (!out) return fail(RT_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    RtContext* ctx = new RtContext();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail(RT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(RtContext* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->collect();
+    for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+    ctx->geom.release(); ctx->mat.release(); ctx->sc.release();
+    ctx->node_a.release(); ctx->node_b.release(); ctx->node_branch.release(); ctx->node_child.release();
+    ctx->level_start.release(); ctx->node_n.release(); ctx->node_nglobal.release(); ctx->node_hits.release();
+    ctx->node_beam.release(); ctx->node_tile0.release(); ctx->node_ntiles.release(); ctx->lvl_ntiles.release();
+    ctx->lvl_tilebase.release(); ctx->flags.release(); ctx->node_start.release(); ctx->node_pre.release();
+    ctx->tile_run.release(); ctx->blk_tot.release();
+    ctx->px.release(); ctx->py.release(); ctx->pz.release(); ctx->dx.release(); ctx->dy.release(); ctx->dz.release(); ctx->nx.release(); ctx->ny.release(); ctx->nz.release();
+    ctx->A.release(); ctx->dist.release(); ctx->cr.release(); ctx->cg.release(); ctx->cb.release();
+    ctx->info.release(); ctx->link.release(); ctx->X.release(); ctx->Y.release(); ctx->samples.release();
+    ctx->image.release(); ctx->sample_off.release();
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!scene || !params) return fail(RT_ERR_INVALID, "scene/params is null");
+    if (scene->n_spheres < 0 || scene->n_spheres > RT_MAX_SPHERES)
+        return fail(RT_ERR_INVALID, "n_spheres %d out of range", scene->n_spheres);
+    if (scene->n_lights < 0 || scene->n_lights > RT_MAX_LIGHTS)
+        return fail(RT_ERR_INVALID, "n_lights %d out of range (max %d)", scene->n_lights, RT_MAX_LIGHTS);
+    if (params->width <= 0 || params->height <= 0) return fail(RT_ERR_INVALID, "image size must be positive");
+    if (scene->n_spheres && (!scene->sphere_geom || !scene->sphere_mat)) return fail(RT_ERR_INVALID, "sphere arrays are null");
+    if (scene->n_lights && !scene->lights) return fail(RT_ERR_INVALID, "lights is null");
+
+    HostTree tree;
+    if (int rc = build_tree(params->max_reflection_depth, params->max_refraction_depth, tree)) return rc;
+    if (tree.n_levels() > MAX_LEVELS) return fail(RT_ERR_INVALID, "more than %d bounce levels", MAX_LEVELS);
+    for (int l = 0; l < tree.n_levels(); ++l)
+        if (tree.level_start[l + 1] - tree.level_start[l] > MAX_LEVEL_NODES)
+            return fail(RT_ERR_INVALID, "ray tree level %d is wider than %d nodes", l, MAX_LEVEL_NODES);
+
+    SceneConst sc{};
+    bool sampled = false;
+    for (int l = 0; l < scene->n_lights; ++l) {
+        const RtLight& L = scene->lights[l];
+        if (L.kind < RT_LIGHT_POINT || L.kind > RT_LIGHT_SPOT) return fail(RT_ERR_INVALID, "light %d: unknown kind %d", l, L.kind);
+        if (L.kind != RT_LIGHT_POINT) {
+            if (L.n_points < 1) return fail(RT_ERR_INVALID, "light %d: n_points must be >= 1", l);
+            sampled = true;
+        }
+        sc.lights[l] = L;
+    }
+    memcpy(sc.ambient, scene->ambient, 24);
+    memcpy(sc.cam, scene->camera_position, 24);
+    memcpy(sc.scr_pos, scene->screen_position, 24);
+    memcpy(sc.scr_x, scene->screen_x, 24);
+    memcpy(sc.scr_y, scene->screen_y, 24);
+    sc.scr_w = scene->screen_width; sc.scr_h = scene->screen_height;
+    sc.pix_x = scene->pixels_x; sc.pix_y = scene->pixels_y;
+    sc.eps = params->epsilon; sc.air = params->air_refractive_index;
+    memcpy(sc.bg, params->background, 24);
+    sc.small_num = params->small_num; sc.width = params->width; sc.height = params->height;
+    sc.n_lights = scene->n_lights;
+
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t S = scene->n_spheres, K = tree.a.size();
+    HIP_TRY(ctx->geom.ensure(S * 4));
+    HIP_TRY(ctx->mat.ensure(S * RT_MAT_WIDTH));
+    HIP_TRY(ctx->sc.ensure(1));
+    if (S) {
+        HIP_TRY(hipMemcpy(ctx->geom.p, scene->sphere_geom, S * 4 * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->mat.p, scene->sphere_mat, S * RT_MAT_WIDTH * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(ctx->sc.p, &sc, sizeof sc, hipMemcpyHostToDevice));
+    HIP_TRY(ctx->node_a.ensure(K)); HIP_TRY(ctx->node_b.ensure(K)); HIP_TRY(ctx->node_branch.ensure(K));
+    HIP_TRY(ctx->node_child.ensure(K * 3)); HIP_TRY(ctx->level_start.ensure(tree.level_start.size()));
+    HIP_TRY(hipMemcpy(ctx->node_a.p, tree.a.data(), K * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->node_b.p, tree.b.data(), K * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->node_branch.p, tree.branch.data(), K * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->node_child.p, tree.child.data(), K * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->level_start.p, tree.level_start.data(), tree.level_start.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx->node_n.ensure(K)); HIP_TRY(ctx->node_nglobal.ensure(K)); HIP_TRY(ctx->node_hits.ensure(K));
+    HIP_TRY(ctx->node_beam.ensure(K * RT_MAX_LIGHTS)); HIP_TRY(ctx->node_tile0.ensure(K)); HIP_TRY(ctx->node_ntiles.ensure(K));
+    HIP_TRY(ctx->node_start.ensure(K)); HIP_TRY(ctx->node_pre.ensure(K * NCNT));
+    HIP_TRY(ctx->lvl_ntiles.ensure(tree.n_levels())); HIP_TRY(ctx->lvl_tilebase.ensure(tree.n_levels()));
+    HIP_TRY(ctx->blk_tot.ensure((size_t)tree.n_levels() * NB * NCNT));
+    HIP_TRY(ctx->flags.ensure(4));
+    HIP_TRY(ctx->sample_off.ensure(K * RT_MAX_LIGHTS));
+
+    ctx->tree = std::move(tree);
+    ctx->sc_host = sc;
+    ctx->params = *params;
+    ctx->S = (int)S;
+    ctx->sampled_lights = sampled;
+    ctx->have_scene = true;
+    ctx->frame_begun = ctx->geometry_done = ctx->layout_set = ctx->shaded = false;
+    return RT_OK;
+}
+
+int rt_begin_frame(RtContext* ctx, int32_t row0, int32_t n_rows, const double* X, const double* Y, int64_t n,
+                   int64_t arena_rays) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->have_scene) return fail(RT_ERR_STATE, "rt_set_scene has not been called");
+    int64_t npix;
+    if (X || Y) {
+        if (!X || !Y || n <= 0) return fail(RT_ERR_INVALID, "X and Y must both be given with n > 0");
+        npix = n;
+    } else {
+        if (row0 < 0 || n_rows <= 0 || row0 + n_rows > ctx->params.height)
+            return fail(RT_ERR_INVALID, "rows [%d, %d) outside the image of height %d", row0, row0 + n_rows, ctx->params.height);
+        npix = (int64_t)n_rows * ctx->params.width;
+    }
+    if (npix > 0x7FFFFFFF) return fail(RT_ERR_INVALID, "too many pixels");
+    if (arena_rays <= 0) arena_rays = std::max<int64_t>(ctx->arena_rays, npix * 24);
+    const int64_t min_rays = ((npix + TILE - 1) / TILE) * TILE;
+    arena_rays = std::max(arena_rays, min_rays);
+    arena_rays = ((arena_rays + TILE - 1) / TILE) * TILE;
+    if (arena_rays >= (int64_t)0xFFFFFFFFu - 2 * TILE) return fail(RT_ERR_INVALID, "ray arena too large for 32-bit ray indices");
+
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t R = (size_t)arena_rays;
+    DevBuf<double>* dbl[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->dx, &ctx->dy, &ctx->dz, &ctx->nx, &ctx->ny, &ctx->nz, &ctx->A, &ctx->dist, &ctx->cr, &ctx->cg, &ctx->cb};
+    for (auto* buf : dbl) HIP_TRY(buf->ensure(R));
+    HIP_TRY(ctx->info.ensure(R));
+    HIP_TRY(ctx->link.ensure(R));
+    HIP_TRY(ctx->tile_run.ensure(R / TILE * NCNT));
+    HIP_TRY(ctx->image.ensure((size_t)npix * 3));
+    ctx->explicit_xy = X != nullptr;
+    if (X) {
+        HIP_TRY(ctx->X.ensure(npix));
+        HIP_TRY(ctx->Y.ensure(npix));
+        HIP_TRY(hipMemcpy(ctx->X.p, X, npix * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->Y.p, Y, npix * sizeof(double), hipMemcpyHostToDevice));
+    }
+    ctx->npix = npix;
+    ctx->row0 = X ? 0 : row0;
+    ctx->arena_rays = arena_rays;
+    ctx->frame_begun = true;
+    ctx->geometry_done = ctx->layout_set = ctx->shaded = false;
+    ctx->next_level = 0;
+    return RT_OK;
+}
+
+int rt_trace_level(RtContext* ctx, int32_t level) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->frame_begun) return fail(RT_ERR_STATE, "rt_begin_frame has not been called");
+    if (level != ctx->next_level) return fail(RT_ERR_STATE, "levels must be traced in order (expected %d, got %d)", ctx->next_level, level);
+    if (level >= ctx->tree.n_levels()) return fail(RT_ERR_INVALID, "level %d out of range", level);
+    if (level == 0) {
+        ctx->begin(RT_K_INIT);
+        hipLaunchKernelGGL(k_init, dim3(1), dim3(1024), 0, ctx->stream, ctx->dev());
+        ctx->end();
+    }
+    if (int rc = launch_level(ctx, level)) return rc;
+    ctx->next_level = level + 1;
+    if (ctx->next_level == ctx->tree.n_levels()) ctx->geometry_done = true;
+    ctx->shaded = false;
+    return RT_OK;
+}
+
+int rt_trace_geometry(RtContext* ctx) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->frame_begun) return fail(RT_ERR_STATE, "rt_begin_frame has not been called");
+    ctx->next_level = 0;
+    for (int l = 0; l < ctx->tree.n_levels(); ++l)
+        if (int rc = rt_trace_level(ctx, l)) return rc;
+    return RT_OK;
+}
+
+int rt_get_level_batches(RtContext* ctx, int32_t level, int64_t* n_local) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->frame_begun || level < 0 || level >= ctx->tree.n_levels() || level > ctx->next_level)
+        return fail(RT_ERR_STATE, "level %d has not been laid out yet", level);
+    if (!n_local) return fail(RT_ERR_INVALID, "n_local is null");
+    const int k0 = ctx->tree.level_start[level], nn = ctx->tree.level_start[level + 1] - k0;
+    std::vector<int32_t> tmp(nn);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), ctx->node_n.p + k0, nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < nn; ++i) n_local[i] = tmp[i];
+    return RT_OK;
+}
+
+int rt_set_global_batches(RtContext* ctx, int32_t level, const int64_t* n_global) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->frame_begun || level < 0 || level >= ctx->tree.n_levels() || level != ctx->next_level)
+        return fail(RT_ERR_STATE, "global batches of level %d must be set right before tracing it", level);
+    if (!n_global) return fail(RT_ERR_INVALID, "n_global is null");
+    const int k0 = ctx->tree.level_start[level], nn = ctx->tree.level_start[level + 1] - k0;
+    std::vector<int32_t> tmp(nn);
+    for (int i = 0; i < nn; ++i) {
+        if (n_global[i] < 0 || n_global[i] > 0x7FFFFFFF) return fail(RT_ERR_INVALID, "batch size out of range");
+        tmp[i] = (int32_t)n_global[i];
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->node_nglobal.p + k0, tmp.data(), nn * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_get_node_counts(RtContext* ctx, int64_t* batch, int64_t* hits, int64_t* beam) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->geometry_done) return fail(RT_ERR_STATE, "geometry phase not finished");
+    const int K = ctx->tree.n_nodes();
+    std::vector<int32_t> n(K), h(K), bm((size_t)K * RT_MAX_LIGHTS);
+    int32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(n.data(), ctx->node_n.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h.data(), ctx->node_hits.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(bm.data(), ctx->node_beam.p, (size_t)K * RT_MAX_LIGHTS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (flag) return fail(RT_ERR_OVERFLOW, "ray arena of %lld rays is too small for this frame", (long long)ctx->arena_rays);
+    for (int k = 0; k < K; ++k) {
+        if (batch) batch[k] = n[k];
+        if (hits) hits[k] = h[k];
+    }
+    if (beam) for (size_t i = 0; i < bm.size(); ++i) beam[i] = bm[i];
+    return RT_OK;
+}
+
+int rt_set_sample_layout(RtContext* ctx, const int64_t* offsets, int64_t total) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->geometry_done) return fail(RT_ERR_STATE, "geometry phase not finished");
+    if (!offsets || total < 0) return fail(RT_ERR_INVALID, "bad sample layout");
+    const size_t n = (size_t)ctx->tree.n_nodes() * RT_MAX_LIGHTS;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx->samples.ensure((size_t)total));
+    HIP_TRY(hipMemcpy(ctx->sample_off.p, offsets, n * sizeof(int64_t), hipMemcpyHostToDevice));
+    ctx->sample_total = total;
+    ctx->layout_set = true;
+    return RT_OK;
+}
+
+int rt_upload_samples(RtContext* ctx, int64_t dst_offset, const double* u, int64_t n) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->layout_set) return fail(RT_ERR_STATE, "rt_set_sample_layout has not been called");
+    if (n < 0 || dst_offset < 0 || dst_offset + n > ctx->sample_total) return fail(RT_ERR_INVALID, "sample range out of bounds");
+    if (n == 0) return RT_OK;
+    if (!u) return fail(RT_ERR_INVALID, "u is null");
+    HIP_TRY(hipMemcpy(ctx->samples.p + dst_offset, u, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int rt_shade(RtContext* ctx) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->geometry_done) return fail(RT_ERR_STATE, "geometry phase not finished");
+    if (ctx->sampled_lights && !ctx->layout_set)
+        return fail(RT_ERR_STATE, "the scene has disk lights: upload their samples before shading");
+    const Dev D = ctx->dev();
+    const bool lds = ctx->S <= SHADE_LDS_SPHERES;
+    for (int level = D.n_levels - 1; level >= 0; --level) {
+        ctx->begin(RT_K_SHADE);
+        if (lds) hipLaunchKernelGGL(k_shade<true>, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
+        else hipLaunchKernelGGL(k_shade<false>, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
+        ctx->end();
+    }
+    HIP_TRY(hipGetLastError());
+    ctx->shaded = true;
+    return RT_OK;
+}
+
+int rt_synchronize(RtContext* ctx) {
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_read_image(RtContext* ctx, double* out_rgb) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->shaded) return fail(RT_ERR_STATE, "rt_shade has not been called for this frame");
+    if (!out_rgb) return fail(RT_ERR_INVALID, "out_rgb is null");
+    int32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(out_rgb, ctx->image.p, (size_t)ctx->npix * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (flag) return fail(RT_ERR_OVERFLOW, "ray arena of %lld rays is too small for this frame", (long long)ctx->arena_rays);
+    return RT_OK;
+}
+
+int rt_image_device_ptr(RtContext* ctx, void** out) {
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!ctx->frame_begun) return fail(RT_ERR_STATE, "rt_begin_frame has not been called");
+    *out = ctx->image.p;
+    return RT_OK;
+}
+
+int rt_get_counters(RtContext* ctx, RtCounters* out) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!out) return fail(RT_ERR_INVALID, "out is null");
+    if (!ctx->geometry_done) return fail(RT_ERR_STATE, "geometry phase not finished");
+    const int K = ctx->tree.n_nodes(), Lv = ctx->tree.n_levels();
+    std::vector<int32_t> n(K), ng(K), h(K), nt(Lv), tb(Lv);
+    int32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(n.data(), ctx->node_n.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ng.data(), ctx->node_nglobal.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h.data(), ctx->node_hits.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(nt.data(), ctx->lvl_ntiles.p, Lv * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(tb.data(), ctx->lvl_tilebase.p, Lv * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memset(out, 0, sizeof *out);
+    out->pixels = ctx->npix;
+    for (int k = 0; k < K; ++k) {
+        if (ng[k] >= ctx->params.small_num) out->rays += n[k];
+        out->hits += h[k];
+    }
+    out->arena_rays_used = (int64_t)(tb[Lv - 1] + nt[Lv - 1]) * TILE;
+    out->arena_capacity = ctx->arena_rays;
+    out->n_nodes = K;
+    out->n_levels = Lv;
+    out->overflow = flag;
+    return RT_OK;
+}
+
+int rt_profile_enable(RtContext* ctx, int32_t on) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!on && ctx->profiling) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->collect();
+    }
+    ctx->profiling = on != 0;
+    return RT_OK;
+}
+
+int rt_get_profile(RtContext* ctx, RtProfile* out, int32_t reset) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!out) return fail(RT_ERR_INVALID, "out is null");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->collect();
+    *out = ctx->prof;
+    if (reset) ctx->prof = RtProfile{};
+    return RT_OK;
+}
+
+int rt_render(RtContext* ctx, double* out_rgb) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->have_scene) return fail(RT_ERR_STATE, "rt_set_scene has not been called");
+    if (ctx->sampled_lights) return fail(RT_ERR_STATE, "rt_render cannot draw disk-light samples; use the phased calls");
+    if (int rc = rt_begin_frame(ctx, 0, ctx->params.height, nullptr, nullptr, 0, 0)) return rc;
+    if (int rc = rt_trace_geometry(ctx)) return rc;
+    if (int rc = rt_shade(ctx)) return rc;
+    return rt_read_image(ctx, out_rgb);
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// Internal definitions shared by the device kernels and the host side of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/raytracing_amd.h"
+
+namespace rt {
+
+constexpr int TILE = 256;             // rays per tile = threads per workgroup
+constexpr int NB = 2048;              // workgroups per level launch (256 CUs x 8)
+constexpr int NCNT = RT_NUM_COUNTERS; // per-tile counters: 3 child kinds, hits, in-beam per light
+constexpr int MAX_LEVELS = 32;
+constexpr int MAX_LEVEL_NODES = 1024; // widest level of the static ray tree we accept
+constexpr int MAX_NODES = 65536;
+constexpr int SPH_CHUNK = 1024;       // spheres staged in LDS per pass of the nearest-hit loop
+constexpr int SHADE_LDS_SPHERES = 512;
+
+// counters
+enum { C_T = 0, C_I = 1, C_R = 2, C_HIT = 3, C_BEAM0 = 4 };
+
+// bits of the per-ray info word
+constexpr uint32_t I_SID_MASK = 0xFFFFu;
+constexpr uint32_t I_HIT = 1u << 16;
+constexpr uint32_t I_INSIDE = 1u << 17;
+constexpr uint32_t I_CHILD_T = 1u << 18;  // spawned a transmitted ray
+constexpr uint32_t I_CHILD_I = 1u << 19;  // spawned a total-internal-reflection ray
+constexpr uint32_t I_CHILD_R = 1u << 20;  // spawned a mirror-reflection ray
+constexpr uint32_t I_LIVE = 1u << 21;     // the ray's colour reaches the pixel with non-zero weight
+constexpr uint32_t I_LIVE_TI = 1u << 22;  // ... and so does its refraction slot
+constexpr uint32_t I_LIVE_R = 1u << 23;   // ... and so does its reflection slot
+constexpr int I_BEAM_SHIFT = 24;          // bit 24 + l: hit lies inside spotlight l's beam
+
+// Scene constants kept in device memory and read through scalar loads.
+struct SceneConst {
+    RtLight lights[RT_MAX_LIGHTS];
+    double ambient[3];
+    double cam[3];
+    double scr_pos[3], scr_x[3], scr_y[3];
+    double scr_w, scr_h, pix_x, pix_y;
+    double eps, air;
+    double bg[3];
+    int32_t small_num, width, height, n_lights;
+};
+
+// Everything a kernel needs, passed by value.
+struct Dev {
+    // scene
+    const double* geom;  // [S][4] centre, radius
+    const double* mat;   // [S][18]
+    const SceneConst* sc;
+    int32_t S;
+    int32_t n_lights;
+    // static tree
+    const int32_t* node_a;
+    const int32_t* node_b;
+    const int32_t* node_branch;
+    const int32_t* node_child;   // [K][3]
+    const int32_t* level_start;  // [n_levels + 1]
+    int32_t K;
+    int32_t n_levels;
+    // per-frame node tables
+    int32_t* node_n;        // local batch size
+    int32_t* node_nglobal;  // whole-image batch size (== node_n on one GPU)
+    int32_t* node_hits;
+    int32_t* node_beam;     // [K][RT_MAX_LIGHTS]
+    int32_t* node_tile0;    // first tile of the node, relative to its level
+    int32_t* node_ntiles;
+    uint32_t* node_start;   // arena index of the node's first ray
+    uint32_t* node_pre;     // [K][NCNT] level-wide running counter value at the node's first tile
+    int32_t* lvl_ntiles;    // [n_levels]
+    int32_t* lvl_tilebase;  // [n_levels] first tile of the level in the arena
+    uint32_t* tile_run;     // [tiles][NCNT] running counter value inside the producing workgroup
+    uint32_t* blk_tot;      // [n_levels][NB][NCNT] per-workgroup totals, turned into prefixes by k_scan
+    int32_t* flags;         // [0] overflow
+    // ray arena (structure of arrays, one slot per ray)
+    double *px, *py, *pz;   // pulled-back hit point
+    double *dx, *dy, *dz;   // ray direction
+    double *nx, *ny, *nz;   // surface normal facing along the ray (the reference's refraction normal)
+    double *A;              // reflected fraction
+    double *dist;           // path length inside the entered sphere (0: no attenuation)
+    uint32_t* info;
+    uint32_t* link;         // arena index of the parent ray
+    double *cr, *cg, *cb;   // ray colour
+    uint32_t cap_tiles;
+    // level-0 pixels
+    const double* X;
+    const double* Y;        // NULL: whole rows starting at row0
+    int32_t row0;
+    int32_t npix;
+    // samples
+    const double* samples;
+    const int64_t* sample_off;  // [K][RT_MAX_LIGHTS]
+    // output
+    double* image;  // [npix][3]
+};
+
+}  // namespace rt

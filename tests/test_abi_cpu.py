@@ -1,0 +1,95 @@
+"""Host-only checks of the C ABI: the library loads, exports every symbol the
+header declares, and its pure-host entry points agree with the Python host
+layer.  No kernel is launched here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytracing_amd import _native
+from raytracing_amd.tree import build_tree, sample_offsets
+from raytracing_amd.flatten import FlatLight, LIGHT_DISK, LIGHT_POINT, LIGHT_SPOT
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "raytracing_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_native.SIGNATURES) == declared
+
+
+def test_struct_sizes_match_the_header_layout():
+    import ctypes as C
+    assert C.sizeof(_native.RtLight) == 16 + 8 * (3 + 1 + 3 + 3 + 1 + 3 + 3 + 3 + 2)
+    assert C.sizeof(_native.RtParams) == 24 + 8 * 5
+    assert C.sizeof(_native.RtCounters) == 5 * 8 + 4 * 4
+    assert C.sizeof(_native.RtScene) == 8 + 3 * 8 + 8 * (5 * 3 + 4)
+
+
+@pytest.mark.parametrize("depths", [(3, 5), (0, 0), (1, 0), (0, 2), (2, 2), (4, 4)])
+def test_native_tree_equals_python_tree(depths):
+    t = build_tree(*depths)
+    n = _native.build_tree_native(*depths)
+    for key in ("a", "b", "parent", "branch", "child", "level", "level_start"):
+        assert np.array_equal(getattr(t, key), n[key]), key
+
+
+def test_tree_of_default_depths():
+    t = build_tree(3, 5)
+    assert t.n_nodes == 644 and t.n_levels == 9
+    assert list(np.diff(t.level_start)) == [1, 3, 9, 27, 65, 131, 191, 161, 56]
+    post = t.post_order()
+    assert sorted(post) == list(range(644)) and post[-1] == 0
+    # children finish before their parent
+    where = np.empty(644, dtype=int)
+    where[post] = np.arange(644)
+    for k in range(1, 644):
+        assert where[k] < where[t.parent[k]]
+
+
+def test_tree_too_large_is_an_error():
+    lib = _native.load_library()
+    import ctypes as C
+    nk, nl = C.c_int32(), C.c_int32()
+    none = C.cast(None, C.POINTER(C.c_int32))
+    rc = lib.rt_build_tree(9, 9, C.byref(nk), C.byref(nl), none, none, none, none, none, none, none)
+    assert rc == _native.RT_ERR_INVALID
+    assert b"nodes" in lib.rt_last_error()
+
+
+def test_device_count_never_fails():
+    assert _native.load_library().rt_device_count() >= 0
+
+
+def test_sample_offsets_follow_post_order():
+    t = build_tree(1, 1)   # root, t-child, i-child, r-child, and the r-child's t-child ...
+    K = t.n_nodes
+    hits = np.arange(1, K + 1) * 2
+    beam = np.zeros((K, 2), dtype=np.int64)
+    beam[:, 1] = np.arange(K)
+    lights = [FlatLight(LIGHT_POINT, np.zeros(3), 1.0, np.ones(3), np.ones(3)),
+              FlatLight(LIGHT_SPOT, np.zeros(3), 1.0, np.ones(3), np.ones(3), n_points=5)]
+    off, cnt, total = sample_offsets(t, lights, hits, beam)
+    cursor = 0
+    for k in t.post_order():
+        assert off[k, 0] == -1
+        if beam[k, 1]:
+            assert off[k, 1] == cursor and cnt[k, 1] == beam[k, 1]
+            cursor += 2 * 5 * beam[k, 1]
+        else:
+            assert off[k, 1] == -1
+    assert total == cursor
+    disk = [FlatLight(LIGHT_DISK, np.zeros(3), 1.0, np.ones(3), np.ones(3), n_points=3)]
+    off, cnt, total = sample_offsets(t, disk, hits, beam)
+    assert total == 2 * 3 * hits.sum()
