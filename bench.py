@@ -1,0 +1,181 @@
+"""Benchmark of the ray-tracing hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 3840 --height 2160]
+
+Workload: the reference's example_1..4 scenes at 3840x2160 (the resolution
+BASELINE.json quotes the metric on), depths (3, 5), example_4 with 30 disk
+samples per hit drawn from NumPy's stream seeded with 0.  One *step* renders
+all four frames: geometry of all bounce levels, lighting/shading and the
+bottom-up colour pass.  Scene buffers and the disk-light samples are resident
+in HBM before the timed region starts (drawing and uploading the samples is
+reported separately as `setup`).
+
+Metric: Mrays/s, rays = rays handed to the nearest-hit search (the
+reference-equivalent count: sum of the batch sizes of all tree nodes whose
+whole-image batch is >= 3), summed over the four frames and all GPUs.
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every
+frame is split into N contiguous row blocks of equal estimated cost; ranks
+exchange per-node batch sizes after every bounce level (the small-batch rule
+needs whole-image sizes) and the image tiles are gathered on rank 0.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+SCENES = ["example_1", "example_2", "example_3", "example_4"]
+FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (half the 157.3 TF packed-FP32 vector peak)
+HBM_PEAK_GBS = 8000.0
+# algorithmic FLOP model: per (ray, sphere) nearest-hit test, per hit, per (hit, light sample)
+# and per (shadow ray, sphere) test
+F_ISECT, F_HIT, F_LIGHT, F_SHADOW = 22, 100, 50, 24
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Time the NumPy float64 oracle on this host: example_1-3 at 500x500 (the
+    reference's default size) as long as the budget allows."""
+    from oracle import numpy_oracle
+    from raytracing_amd.Scenes.scenes import build_scene
+    rays, spent, used = 0, 0.0, []
+    for name in SCENES[:3]:
+        if spent > seconds_budget:
+            break
+        scene = build_scene(name, 500, 500)
+        t0 = time.perf_counter()
+        _, stats = numpy_oracle.render(scene, seed=0)
+        spent += time.perf_counter() - t0
+        rays += stats.traced_rays()
+        used.append(name)
+    threads = int(os.environ.get("OPENBLAS_NUM_THREADS", os.environ.get("OMP_NUM_THREADS", "0")) or 0)
+    return {"value": rays / spent / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"NumPy float64 oracle, {'+'.join(used)} at 500x500, {rays} rays in {spent:.1f} s "
+                      f"(NumPy elementwise code is single-threaded; BLAS threads setting {threads or 'default'}, "
+                      f"host has {os.cpu_count()} logical CPUs)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--scenes", nargs="*", default=SCENES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from raytracing_amd.distributed import FrameJob, init_group
+
+    rank, world, group = init_group(args.gpus)
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    W, H = args.width, args.height
+
+    # ---- set-up: geometry once, then draw + upload the disk-light samples -------------------
+    t_setup = time.perf_counter()
+    jobs = []
+    for name in args.scenes:
+        job = FrameJob(name, W, H, device=local_rank, rank=rank, world=world, group=group)
+        np.random.seed(0)
+        job.prepare()            # first geometry pass, row split, samples resident in HBM
+        jobs.append(job)
+    setup_s = time.perf_counter() - t_setup
+
+    def step():
+        for job in jobs:
+            job.step()           # geometry + shade, asynchronous on the job's stream
+
+    def sync_all():
+        for job in jobs:
+            job.synchronize()
+        if world > 1:
+            torch.distributed.barrier(group=group)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    for job in jobs:
+        job.profile(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    for job in jobs:
+        job.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+        elapsed = float(t.item())
+
+    # ---- bookkeeping ----------------------------------------------------------------------
+    stats = [job.stats() for job in jobs]            # global (all-rank) counts per frame
+    prof = {}
+    for job in jobs:
+        for kind, rec in job.profile(reset=False).items():
+            acc = prof.setdefault(kind, {"ms": 0.0, "launches": 0})
+            acc["ms"] += rec["ms"]
+            acc["launches"] += rec["launches"]
+    if rank != 0:
+        for job in jobs:
+            job.close()
+        return
+
+    rays = sum(s["rays"] for s in stats)
+    hits = sum(s["hits"] for s in stats)
+    shadow_rays = sum(s["shadow_rays"] for s in stats)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = rays / (elapsed / args.steps) / 1e6
+
+    # dominant kernel = the kind with the largest accumulated device time on rank 0
+    dominant = max(prof, key=lambda k: prof[k]["ms"])
+    local = [job.local_stats() for job in jobs]      # this rank's share, what its kernels executed
+    flops = {
+        "trace": sum(F_ISECT * s["rays"] * s["spheres"] + F_HIT * s["hits"] for s in local),
+        "shade": sum((F_LIGHT + F_SHADOW * s["spheres"]) * s["shaded_samples"] for s in local),
+    }
+    roofline = None
+    if dominant in flops and prof[dominant]["launches"]:
+        per_launch_ms = prof[dominant]["ms"] / prof[dominant]["launches"]
+        launches_per_step = prof[dominant]["launches"] / args.steps
+        tflops = flops[dominant] / launches_per_step / (per_launch_ms * 1e-3) / 1e12
+        roofline = {"kernel": "k_" + dominant, "bound": "valu", "dtype": "f64",
+                    "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step,
+                    "flops_per_step": flops[dominant]}
+
+    out = {
+        "metric": "Mrays/s (primary+secondary) at 3840x2160 example scenes",
+        "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{'+'.join(args.scenes)} at {W}x{H}, depths (3,5), example_4 with 30 disk samples/hit "
+                               f"(seed 0); one step = all frames, geometry + shading",
+                   "rays_per_step": rays, "hits_per_step": hits, "shadow_rays_per_step": shadow_rays,
+                   "rows_split": "contiguous cost-balanced row blocks" if world > 1 else "none"},
+        "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+        "setup_s": setup_s,
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    for job in jobs:
+        job.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

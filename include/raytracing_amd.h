@@ -107,6 +107,9 @@ typedef struct RtCounters {
     int64_t rays;            /* rays handed to the nearest-hit search (local batches in
                                 nodes whose global batch is >= small_num)              */
     int64_t hits;            /* of those, rays that hit a sphere                       */
+    int64_t shaded_hits;     /* hits whose surface colour was evaluated by rt_shade (hits
+                                with zero weight in the pixel are skipped)             */
+    int64_t shaded_samples;  /* light samples evaluated for them = shadow rays cast    */
     int64_t arena_rays_used; /* ray slots used, including tile padding                 */
     int64_t arena_capacity;  /* ray slots allocated                                    */
     int32_t n_nodes;         /* nodes of the static ray tree                           */
@@ -195,6 +198,11 @@ int rt_upload_samples(RtContext *ctx, int64_t dst_offset, const double *u, int64
  * clipped pixel colours (reference raytrace.py:15) on the device.  Does not
  * synchronise. */
 int rt_shade(RtContext *ctx);
+
+/* Optional: have rt_shade write the colours into caller-owned DEVICE memory
+ * ([n_pixels][3] float64, e.g. a torch tensor's data_ptr) instead of the
+ * context's own buffer.  NULL switches back.  Call after rt_begin_frame. */
+int rt_set_output(RtContext *ctx, void *device_rgb);
 
 /* Copy the frame's colours, [n_pixels][3] float64 in pixel order (synchronises). */
 int rt_read_image(RtContext *ctx, double *out_rgb);

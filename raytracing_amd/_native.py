@@ -58,6 +58,7 @@ class RtParams(C.Structure):
 
 class RtCounters(C.Structure):
     _fields_ = [("pixels", C.c_int64), ("rays", C.c_int64), ("hits", C.c_int64),
+                ("shaded_hits", C.c_int64), ("shaded_samples", C.c_int64),
                 ("arena_rays_used", C.c_int64), ("arena_capacity", C.c_int64),
                 ("n_nodes", C.c_int32), ("n_levels", C.c_int32), ("overflow", C.c_int32), ("reserved", C.c_int32)]
 
@@ -88,6 +89,7 @@ SIGNATURES = {
     "rt_set_sample_layout": (C.c_int, [_P, _I64P, C.c_int64]),
     "rt_upload_samples": (C.c_int, [_P, C.c_int64, _F64P, C.c_int64]),
     "rt_shade": (C.c_int, [_P]),
+    "rt_set_output": (C.c_int, [_P, _P]),
     "rt_read_image": (C.c_int, [_P, _F64P]),
     "rt_image_device_ptr": (C.c_int, [_P, C.POINTER(_P)]),
     "rt_synchronize": (C.c_int, [_P]),
@@ -268,6 +270,10 @@ class Context:
 
     def shade(self):
         _check(self.lib.rt_shade(self._h))
+
+    def set_output(self, device_ptr):
+        """Write the frame into caller-owned device memory (None: the context's own buffer)."""
+        _check(self.lib.rt_set_output(self._h, _P(device_ptr) if device_ptr else None))
 
     def read_image(self):
         out = np.empty((self.npix, 3), dtype=np.float64)

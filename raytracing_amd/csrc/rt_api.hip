@@ -111,6 +111,8 @@ struct RtContext {
     DevBuf<uint32_t> info, link;
     DevBuf<double> X, Y, samples, image;
     DevBuf<int64_t> sample_off;
+    DevBuf<unsigned long long> work;
+    double* user_image = nullptr;
 
     int64_t npix = 0;
     int row0 = 0;
@@ -132,14 +134,14 @@ struct RtContext {
         D.node_n = node_n.p; D.node_nglobal = node_nglobal.p; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
         D.node_tile0 = node_tile0.p; D.node_ntiles = node_ntiles.p; D.node_start = node_start.p; D.node_pre = node_pre.p;
         D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p;
-        D.flags = flags.p;
+        D.flags = flags.p; D.work = work.p;
         D.px = px.p; D.py = py.p; D.pz = pz.p; D.dx = dx.p; D.dy = dy.p; D.dz = dz.p; D.nx = nx.p; D.ny = ny.p; D.nz = nz.p; D.A = A.p; D.dist = dist.p;
         D.info = info.p; D.link = link.p; D.cr = cr.p; D.cg = cg.p; D.cb = cb.p;
         D.cap_tiles = (uint32_t)(arena_rays / TILE);
         D.X = explicit_xy ? X.p : nullptr; D.Y = explicit_xy ? Y.p : nullptr;
         D.row0 = row0; D.npix = (int32_t)npix;
         D.samples = samples.p; D.sample_off = sample_off.p;
-        D.image = image.p;
+        D.image = user_image ? user_image : image.p;
         return D;
     }
 
@@ -270,7 +272,7 @@ void rt_destroy(RtContext* ctx) {
     ctx->px.release(); ctx->py.release(); ctx->pz.release(); ctx->dx.release(); ctx->dy.release(); ctx->dz.release(); ctx->nx.release(); ctx->ny.release(); ctx->nz.release();
     ctx->A.release(); ctx->dist.release(); ctx->cr.release(); ctx->cg.release(); ctx->cb.release();
     ctx->info.release(); ctx->link.release(); ctx->X.release(); ctx->Y.release(); ctx->samples.release();
-    ctx->image.release(); ctx->sample_off.release();
+    ctx->image.release(); ctx->sample_off.release(); ctx->work.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -339,6 +341,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     HIP_TRY(ctx->lvl_ntiles.ensure(tree.n_levels())); HIP_TRY(ctx->lvl_tilebase.ensure(tree.n_levels()));
     HIP_TRY(ctx->blk_tot.ensure((size_t)tree.n_levels() * NB * NCNT));
     HIP_TRY(ctx->flags.ensure(4));
+    HIP_TRY(ctx->work.ensure(4));
     HIP_TRY(ctx->sample_off.ensure(K * RT_MAX_LIGHTS));
 
     ctx->tree = std::move(tree);
@@ -386,6 +389,7 @@ int rt_begin_frame(RtContext* ctx, int32_t row0, int32_t n_rows, const double* X
         HIP_TRY(hipMemcpy(ctx->X.p, X, npix * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->Y.p, Y, npix * sizeof(double), hipMemcpyHostToDevice));
     }
+    ctx->user_image = nullptr;
     ctx->npix = npix;
     ctx->row0 = X ? 0 : row0;
     ctx->arena_rays = arena_rays;
@@ -398,9 +402,12 @@ int rt_begin_frame(RtContext* ctx, int32_t row0, int32_t n_rows, const double* X
 int rt_trace_level(RtContext* ctx, int32_t level) {
     if (int rc = use_device(ctx)) return rc;
     if (!ctx->frame_begun) return fail(RT_ERR_STATE, "rt_begin_frame has not been called");
-    if (level != ctx->next_level) return fail(RT_ERR_STATE, "levels must be traced in order (expected %d, got %d)", ctx->next_level, level);
-    if (level >= ctx->tree.n_levels()) return fail(RT_ERR_INVALID, "level %d out of range", level);
+    if (level != ctx->next_level && level != 0)
+        return fail(RT_ERR_STATE, "levels must be traced in order (expected %d or 0, got %d)", ctx->next_level, level);
+    if (level < 0 || level >= ctx->tree.n_levels()) return fail(RT_ERR_INVALID, "level %d out of range", level);
     if (level == 0) {
+        // (re)start the frame on the pixels chosen by the last rt_begin_frame
+        ctx->geometry_done = false;
         ctx->begin(RT_K_INIT);
         hipLaunchKernelGGL(k_init, dim3(1), dim3(1024), 0, ctx->stream, ctx->dev());
         ctx->end();
@@ -511,6 +518,13 @@ int rt_shade(RtContext* ctx) {
     return RT_OK;
 }
 
+int rt_set_output(RtContext* ctx, void* device_rgb) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->frame_begun) return fail(RT_ERR_STATE, "rt_begin_frame has not been called");
+    ctx->user_image = (double*)device_rgb;
+    return RT_OK;
+}
+
 int rt_synchronize(RtContext* ctx) {
     if (int rc = use_device(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -522,7 +536,8 @@ int rt_read_image(RtContext* ctx, double* out_rgb) {
     if (!ctx->shaded) return fail(RT_ERR_STATE, "rt_shade has not been called for this frame");
     if (!out_rgb) return fail(RT_ERR_INVALID, "out_rgb is null");
     int32_t flag = 0;
-    HIP_TRY(hipMemcpyAsync(out_rgb, ctx->image.p, (size_t)ctx->npix * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_rgb, ctx->user_image ? ctx->user_image : ctx->image.p, (size_t)ctx->npix * 3 * sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (flag) return fail(RT_ERR_OVERFLOW, "ray arena of %lld rays is too small for this frame", (long long)ctx->arena_rays);
@@ -532,7 +547,7 @@ int rt_read_image(RtContext* ctx, double* out_rgb) {
 int rt_image_device_ptr(RtContext* ctx, void** out) {
     if (!ctx || !out) return fail(RT_ERR_INVALID, "null argument");
     if (!ctx->frame_begun) return fail(RT_ERR_STATE, "rt_begin_frame has not been called");
-    *out = ctx->image.p;
+    *out = ctx->user_image ? ctx->user_image : ctx->image.p;
     return RT_OK;
 }
 
@@ -543,6 +558,8 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     const int K = ctx->tree.n_nodes(), Lv = ctx->tree.n_levels();
     std::vector<int32_t> n(K), ng(K), h(K), nt(Lv), tb(Lv);
     int32_t flag = 0;
+    unsigned long long work[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(work, ctx->work.p, sizeof work, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(n.data(), ctx->node_n.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ng.data(), ctx->node_nglobal.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(h.data(), ctx->node_hits.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -556,6 +573,8 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
         if (ng[k] >= ctx->params.small_num) out->rays += n[k];
         out->hits += h[k];
     }
+    out->shaded_hits = (int64_t)work[0];
+    out->shaded_samples = (int64_t)work[1];
     out->arena_rays_used = (int64_t)(tb[Lv - 1] + nt[Lv - 1]) * TILE;
     out->arena_capacity = ctx->arena_rays;
     out->n_nodes = K;

@@ -73,6 +73,7 @@ struct Dev {
     uint32_t* tile_run;     // [tiles][NCNT] running counter value inside the producing workgroup
     uint32_t* blk_tot;      // [n_levels][NB][NCNT] per-workgroup totals, turned into prefixes by k_scan
     int32_t* flags;         // [0] overflow
+    unsigned long long* work;  // [0] hits shaded, [1] light samples evaluated (cleared by k_init)
     // ray arena (structure of arrays, one slot per ray)
     double *px, *py, *pz;   // pulled-back hit point
     double *dx, *dy, *dz;   // ray direction

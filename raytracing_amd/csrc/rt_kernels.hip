@@ -105,6 +105,8 @@ __global__ void k_init(Dev D) {
     if (tid == 0) {
         int nt = (D.npix + TILE - 1) / TILE;
         D.flags[0] = 0;
+        D.work[0] = 0;
+        D.work[1] = 0;
         if ((uint32_t)nt > D.cap_tiles) {
             D.flags[0] = 1;
             nt = 0;
@@ -523,7 +525,7 @@ __device__ __forceinline__ double ease(int mode, double x, double a, double d) {
 // node's hits / in-beam hits; h_hit / h_beam: those counts.
 template <bool LDS>
 __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int node, uint32_t info, V3 Pb, V3 d, V3 n,
-                            const double* m, int j_hit, int h_hit, const int* j_beam) {
+                            const double* m, int j_hit, int h_hit, const int* j_beam, unsigned& n_samples) {
     const SceneConst& sc = *D.sc;
     const V3 kdiff = ld3(m + 3), kspec = ld3(m + 6);
     const double shin = m[9];
@@ -545,6 +547,7 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int node, ui
             const double rd = fabs(dot(Rv, d));
             V3 kd = clip01(nl * kdiff), ks = clip01(pow_shininess(rd, shin) * kspec);
             surf = surf + clip01(clip01(kd * Id) + clip01(ks * Is));
+            n_samples += 1;
             continue;
         }
         // disk light, possibly restricted to a beam
@@ -562,6 +565,7 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int node, ui
             factor = ease(Lt.easing, rho, allowed, edge - allowed);
         }
         const int N = Lt.n_points;
+        n_samples += N;
         const int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
         const double* u_theta = D.samples + off + j;
         const double* u_rad = D.samples + off + (int64_t)N * h + j;
@@ -606,8 +610,11 @@ __global__ __launch_bounds__(TILE) void k_shade(Dev D, int level) {
     __shared__ int s_tile_end[MAX_LEVEL_NODES];
     __shared__ int s_wcnt[4][NCNT];
     __shared__ ShadowSphere s_sh[LDS ? SHADE_LDS_SPHERES : 1];
+    __shared__ unsigned s_work[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (D.flags[0]) return;  // arena overflow: the frame is invalid, the host reports it
+    if (tid < 2) s_work[tid] = 0;
+    unsigned my_hits = 0, my_samples = 0;
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
     for (int i = tid; i < nn; i += TILE) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
     const int nt = D.lvl_ntiles[level];
@@ -668,7 +675,8 @@ __global__ __launch_bounds__(TILE) void k_shade(Dev D, int level) {
                         V3 N = {D.nx[idx], D.ny[idx], D.nz[idx]};
                         V3 n = inside ? N : -N;  // outward normal
                         surf = surface_color<LDS>(D, s_sh, k, info, Pb, d, n, m, rank[C_HIT], D.node_hits[k],
-                                                  rank + C_BEAM0);
+                                                  rank + C_BEAM0, my_samples);
+                        my_hits += 1;
                     }
                     V3 refr = {0, 0, 0}, refl = {0, 0, 0};
                     if ((info & I_LIVE_TI) && (info & (I_CHILD_T | I_CHILD_I))) {
@@ -700,6 +708,12 @@ __global__ __launch_bounds__(TILE) void k_shade(Dev D, int level) {
         }
         __syncthreads();
     }
+    if (my_hits) {
+        atomicAdd(&s_work[0], my_hits);
+        atomicAdd(&s_work[1], my_samples);
+    }
+    __syncthreads();
+    if (tid < 2 && s_work[tid]) atomicAdd(&D.work[tid], (unsigned long long)s_work[tid]);
 }
 
 template __global__ void k_shade<true>(Dev, int);

@@ -1,0 +1,384 @@
+"""Rendering one frame on several GPUs of a node (one process per GPU).
+
+The image is cut into contiguous blocks of rows, one per rank.  Pixels are
+independent except for two whole-image couplings of the reference's batch
+recursion, and both are exchanged here:
+
+* the small-batch rule (reference raytrace.py:26-27) compares the size of a
+  tree node's batch *over the whole image* with ``SMALL_NUM``: after every
+  bounce level the ranks sum their per-node batch sizes (a few hundred
+  integers) and hand the totals to the device before the next level is traced;
+* disk-light random numbers (reference objects.py:132-133) are consumed in one
+  global order: sample ``s`` of the ``j``-th hit (in pixel order) of a node
+  reads element ``s * h + j`` of the node's block, ``h`` being the node's hit
+  count over the whole image.  With contiguous row blocks the hits of rank
+  ``r`` are the index range ``[base_r, base_r + h_r)`` of every node, so each
+  rank draws the stream and keeps the columns that belong to its rows.
+
+Row blocks are sized by a low-resolution probe render so that every rank gets
+about the same estimated work (sky rows cost almost nothing).  The finished
+tiles are sent to rank 0 with point-to-point transfers (RCCL over xGMI when
+the tensors live on GPUs).
+
+All collective traffic goes through :class:`Comm`, a thin wrapper over
+``torch.distributed`` that works with the ``nccl`` (= RCCL) backend on GPUs and
+with ``gloo`` on CPUs; the device work goes through a *backend* object with the
+methods of :class:`raytracing_amd._native.Context`.
+"""
+import os
+
+import numpy as np
+
+from .constants import RenderParams
+from .flatten import FlatScene, flatten_scene, LIGHT_SPOT
+from .tree import build_tree, sample_offsets
+
+PROBE_SCALE = 8       # the probe frame is 1/8 of the resolution in each direction
+PROBE_BANDS = 64
+SAMPLE_CHUNK = 1 << 24
+# same FLOP weights as the benchmark's model
+F_ISECT, F_HIT, F_LIGHT, F_SHADOW = 22, 100, 50, 24
+
+
+# ----------------------------------------------------------------------------------------------
+class Comm:
+    """The handful of collectives the renderer needs, on NumPy arrays."""
+
+    def __init__(self, group=None, device=None):
+        self.group = group
+        self.device = device          # torch device the backend's tensors must live on
+        if group is None:
+            self.rank, self.world = 0, 1
+        else:
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def _t(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(self.device) if self.device is not None else t
+
+    def all_reduce_sum(self, a):
+        if self.world == 1:
+            return np.asarray(a)
+        import torch.distributed as dist
+        t = self._t(a)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def all_gather(self, a):
+        """Stack every rank's array (same shape everywhere) along a new first axis."""
+        a = np.asarray(a)
+        if self.world == 1:
+            return a[None]
+        import torch
+        import torch.distributed as dist
+        t = self._t(a)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return np.stack([o.cpu().numpy() for o in out])
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.group)
+
+    def gather_tiles(self, full, tile, bounds, width):
+        """Point-to-point gather of row tiles into ``full`` on rank 0.  ``full`` and
+        ``tile`` are torch tensors of shape (rows * width, 3); rank 0's own tile is
+        expected to be a view of ``full`` already."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        ops = []
+        if self.rank == 0:
+            for r in range(1, self.world):
+                lo, hi = int(bounds[r]) * width, int(bounds[r + 1]) * width
+                if hi > lo:
+                    ops.append(dist.P2POp(dist.irecv, full[lo:hi], dist.get_global_rank(self.group, r) if self.group else r,
+                                          group=self.group))
+        elif tile.numel():
+            ops.append(dist.P2POp(dist.isend, tile, dist.get_global_rank(self.group, 0) if self.group else 0,
+                                  group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+
+def init_group(n_gpus):
+    """Join the process group created by ``torch.distributed.run`` (one rank per
+    GPU, RCCL).  Returns ``(rank, world, group)``; a single process gets
+    ``(0, 1, None)`` without touching torch.distributed."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, None
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size(), dist.group.WORLD
+
+
+# ----------------------------------------------------------------------------------------------
+def frame_cost(flat, rays, hits):
+    """Estimated work of a pixel set from its ray and hit counts."""
+    S = flat.n_spheres
+    per_hit = F_HIT + sum(l.n_points * (F_LIGHT + F_SHADOW * S) for l in flat.lights)
+    return F_ISECT * S * rays + per_hit * hits
+
+
+def split_rows(height, world, band_rows, band_cost):
+    """Row boundaries ``(world + 1,)`` that give every rank the same share of the
+    piecewise-constant cost density described by bands starting at ``band_rows``
+    (plus the end row) with total cost ``band_cost`` each.  Every rank gets at
+    least one row when ``height >= world``."""
+    band_rows = np.asarray(band_rows, dtype=np.int64)
+    cost = np.maximum(np.asarray(band_cost, dtype=np.float64), 0.0)
+    n_rows = np.diff(band_rows)
+    per_row = np.repeat(cost / np.maximum(n_rows, 1), n_rows) + 1e-9 * max(cost.sum(), 1.0) / height
+    cum = np.concatenate([[0.0], np.cumsum(per_row)])
+    targets = cum[-1] * np.arange(1, world) / world
+    cuts = np.searchsorted(cum, targets, side="left")
+    bounds = np.concatenate([[0], cuts, [height]]).astype(np.int64)
+    if height >= world:
+        for r in range(1, world + 1):                     # at least one row each, monotone
+            bounds[r] = max(bounds[r], bounds[r - 1] + 1)
+        for r in range(world - 1, -1, -1):
+            bounds[r] = min(bounds[r], bounds[r + 1] - 1)
+    return np.maximum.accumulate(bounds)
+
+
+class ShardedRenderer:
+    """One rank's part of a frame that is split over ``comm.world`` ranks."""
+
+    def __init__(self, scene, params, comm, backend, probe_backend=None):
+        self.flat = scene if isinstance(scene, FlatScene) else flatten_scene(scene)
+        if params is None:
+            params = RenderParams(width=int(self.flat.pixels_x), height=int(self.flat.pixels_y))
+        self.params = params
+        self.comm = comm
+        self.tree = build_tree(params.max_reflection_depth, params.max_refraction_depth)
+        self.ctx = backend
+        self.probe_ctx = probe_backend if probe_backend is not None else backend
+        self.bounds = None
+        self.arena_rays = 0
+        self.rays_per_pixel = 24
+        self.global_hits = self.global_beam = self.global_batch = None
+        self.local_hits = self.local_beam = self.local_batch = None
+        self.samples_total = 0
+
+    # ---- row split -----------------------------------------------------------------------
+    def probe_costs(self):
+        """Render the frame at 1/PROBE_SCALE resolution in bands of rows (geometry only)
+        and return ``(band_rows_fullres, band_cost)``."""
+        import copy
+        p, f = self.params, self.flat
+        pw, ph = max(1, p.width // PROBE_SCALE), max(1, p.height // PROBE_SCALE)
+        probe_flat = copy.copy(f)
+        probe_flat.pixels_x, probe_flat.pixels_y = float(pw), float(ph)
+        probe_params = copy.copy(p)
+        probe_params.width, probe_params.height = pw, ph
+        ctx = self.probe_ctx
+        ctx.set_scene(probe_flat, probe_params, self.tree)
+        n_bands = min(PROBE_BANDS, ph)
+        edges = np.linspace(0, ph, n_bands + 1).round().astype(np.int64)
+        cost = np.zeros(n_bands)
+        for i in range(n_bands):
+            r0, r1 = int(edges[i]), int(edges[i + 1])
+            if r1 <= r0:
+                continue
+            arena = 64 * (r1 - r0) * pw + 4096
+            while True:
+                ctx.begin_rows(r0, r1 - r0, pw, arena)
+                ctx.trace_geometry()
+                c = ctx.counters()
+                if not c["overflow"]:
+                    break
+                arena *= 2
+            cost[i] = frame_cost(f, c["rays"], c["hits"])
+        rows = np.minimum(edges * p.height // ph, p.height)
+        rows[-1] = p.height
+        return rows, cost
+
+    def choose_rows(self):
+        if self.comm.world == 1:
+            self.bounds = np.array([0, self.params.height], dtype=np.int64)
+        else:
+            rows, cost = self.probe_costs()
+            self.bounds = split_rows(self.params.height, self.comm.world, rows, cost)
+        self.ctx.set_scene(self.flat, self.params, self.tree)
+        return self.bounds
+
+    @property
+    def my_rows(self):
+        return int(self.bounds[self.comm.rank]), int(self.bounds[self.comm.rank + 1])
+
+    # ---- phases --------------------------------------------------------------------------
+    def begin(self, output_ptr=None):
+        r0, r1 = self.my_rows
+        n = max(r1 - r0, 0)
+        if not self.arena_rays:
+            self.arena_rays = self.rays_per_pixel * max(n, 1) * self.params.width
+        self.ctx.begin_rows(r0, max(n, 1) if n == 0 else n, self.params.width, self.arena_rays)
+        if output_ptr:
+            self.ctx.set_output(output_ptr)
+
+    def trace(self):
+        """Geometry phase with the per-level exchange of batch sizes."""
+        ctx, comm = self.ctx, self.comm
+        if comm.world == 1:
+            ctx.trace_geometry()
+            return
+        for level in range(self.tree.n_levels):
+            if level > 0:
+                ctx.set_global_batches(level, comm.all_reduce_sum(ctx.level_batches(level)))
+            ctx.trace_level(level)
+
+    def trace_checked(self, output_ptr=None):
+        """trace() with arena-overflow handling: every rank doubles its arena and
+        retries while any rank overflowed."""
+        while True:
+            self.begin(output_ptr)
+            self.trace()
+            overflow = int(self.ctx.counters()["overflow"])
+            if int(self.comm.all_reduce_sum(np.array([overflow], dtype=np.int64))[0]) == 0:
+                break
+            self.arena_rays *= 2
+        self.collect_counts()
+
+    def collect_counts(self):
+        batch, hits, beam = self.ctx.node_counts()
+        self.local_batch, self.local_hits, self.local_beam = batch, hits, beam
+        packed = np.concatenate([batch[:, None], hits[:, None], beam], axis=1).astype(np.int64)
+        every = self.comm.all_gather(packed)                      # (world, K, 2 + L)
+        self.rank_hits = every[:, :, 1]
+        self.rank_beam = every[:, :, 2:]
+        self.global_batch = every[:, :, 0].sum(axis=0)
+        self.global_hits = self.rank_hits.sum(axis=0)
+        self.global_beam = self.rank_beam.sum(axis=0)
+
+    def draw_samples(self, rng=None):
+        """Draw the whole image's disk-light uniforms in the reference's order from
+        ``rng`` (default: NumPy's global stream) and upload this rank's columns."""
+        if not self.flat.has_sampled_lights:
+            return 0
+        rng = np.random if rng is None else rng
+        lights, r = self.flat.lights, self.comm.rank
+        g_off, g_cnt, g_total = sample_offsets(self.tree, lights, self.global_hits, self.global_beam)
+        l_off, l_cnt, l_total = sample_offsets(self.tree, lights, self.local_hits, self.local_beam)
+        self.ctx.set_sample_layout(l_off, l_total)
+        self.samples_total = l_total
+        if self.comm.world == 1:
+            for pos in range(0, g_total, SAMPLE_CHUNK):
+                self.ctx.upload_samples(pos, rng.random(min(SAMPLE_CHUNK, g_total - pos)))
+            return g_total
+        for node in self.tree.post_order():
+            for l, light in enumerate(lights):
+                h = int(g_cnt[node, l])
+                if h == 0:
+                    continue
+                per_rank = self.rank_beam[:, node, l] if light.kind == LIGHT_SPOT else self.rank_hits[:, node]
+                base, mine = int(per_rank[:r].sum()), int(per_rank[r])
+                N = light.n_points
+                rows_per_draw = max(1, SAMPLE_CHUNK // h)
+                for part in range(2):                              # all angles, then all radii
+                    for s0 in range(0, N, rows_per_draw):
+                        s1 = min(N, s0 + rows_per_draw)
+                        u = rng.random((s1 - s0) * h)
+                        if mine:
+                            cols = u.reshape(s1 - s0, h)[:, base:base + mine]
+                            self.ctx.upload_samples(int(l_off[node, l]) + (part * N + s0) * mine, cols)
+        return g_total
+
+    def shade(self):
+        self.ctx.shade()
+
+    # ---- statistics ------------------------------------------------------------------------
+    def global_stats(self):
+        small = self.params.small_num
+        rays = int(self.global_batch[self.global_batch >= small].sum())
+        c = self.ctx.counters()
+        extra = self.comm.all_reduce_sum(np.array([c["shaded_hits"], c["shaded_samples"]], dtype=np.int64))
+        return {"rays": rays, "hits": int(self.global_hits.sum()), "shaded_hits": int(extra[0]),
+                "shadow_rays": int(extra[1]), "spheres": self.flat.n_spheres}
+
+    def local_stats(self):
+        c = self.ctx.counters()
+        return {"rays": int(c["rays"]), "hits": int(c["hits"]), "shaded_hits": int(c["shaded_hits"]),
+                "shaded_samples": int(c["shaded_samples"]), "spheres": self.flat.n_spheres}
+
+
+# ----------------------------------------------------------------------------------------------
+class FrameJob:
+    """A benchmark frame on the GPUs of this process group: set-up once, then
+    ``step()`` re-renders it with the samples already resident in HBM."""
+
+    def __init__(self, scene_name, width, height, device=0, rank=0, world=1, group=None):
+        import torch
+        from . import _native
+        from .Scenes.scenes import build_scene
+        self.torch = torch
+        self.name = scene_name
+        self.device = torch.device("cuda", device)
+        self.comm = Comm(group, self.device if world > 1 else None)
+        scene = build_scene(scene_name, width, height)
+        params = RenderParams(width=width, height=height)
+        # one private stream per frame on a single GPU (frames overlap); torch's current
+        # stream when tiles are exchanged, so the transfers are ordered after the kernels
+        stream = torch.cuda.current_stream(self.device).cuda_stream if world > 1 else None
+        self.ctx = _native.Context(device, stream)
+        self.r = ShardedRenderer(scene, params, self.comm, self.ctx)
+        self.width, self.height = width, height
+        self.full = self.tile = None
+
+    def prepare(self):
+        torch, r = self.torch, self.r
+        r.choose_rows()
+        r0, r1 = r.my_rows
+        W = self.width
+        if self.comm.world > 1:
+            if self.comm.rank == 0:
+                self.full = torch.empty((self.height * W, 3), dtype=torch.float64, device=self.device)
+                self.tile = self.full[r0 * W:r1 * W]
+            else:
+                self.tile = torch.empty(((r1 - r0) * W, 3), dtype=torch.float64, device=self.device)
+        r.trace_checked(self.tile.data_ptr() if self.tile is not None else None)
+        r.draw_samples()
+        self.ctx.profile_enable(True)
+        self.step()
+        self.synchronize()
+        self._stats = r.global_stats()
+        self._local = r.local_stats()
+
+    def step(self):
+        r = self.r
+        r.trace()
+        r.shade()
+        if self.comm.world > 1:
+            self.comm.gather_tiles(self.full, self.tile, r.bounds, self.width)
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    def image(self):
+        """Rank 0: the whole frame as a NumPy array (other ranks: their tile)."""
+        if self.comm.world == 1:
+            return self.ctx.read_image().reshape(self.height, self.width, 3)
+        self.synchronize()
+        self.torch.cuda.synchronize()
+        t = self.full if self.comm.rank == 0 else self.tile
+        return t.cpu().numpy().reshape(-1, self.width, 3)
+
+    def profile(self, reset=False):
+        return self.ctx.profile(reset)
+
+    def stats(self):
+        return self._stats
+
+    def local_stats(self):
+        return self._local
+
+    def close(self):
+        self.ctx.close()
