@@ -202,12 +202,19 @@ class Oracle:
         i_s = light.specular_color * intensity / dist ** 2 * mult
         return np.clip(i_d, 0, 1), np.clip(i_s, 0, 1), Lu
 
-    def _disk_light(self, light, P):
+    def _draw(self, light_index, count):
+        """The two uniform blocks of one disk-light evaluation: all angles first,
+        then all radii (reference objects.py:132-133).  Subclasses may serve them
+        from an uploaded buffer instead of the random stream."""
+        return self.rng.random(count), self.rng.random(count)
+
+    def _disk_light(self, light, P, light_index=0):
         h = P.shape[0]
         N = light.n_points
         tiled = np.tile(P, (N, 1))
-        theta = self.rng.random(N * h) * 2 * math.pi
-        rad = self.rng.random(N * h) ** 0.5 * light.radius
+        u_theta, u_rad = self._draw(light_index, N * h)
+        theta = u_theta * 2 * math.pi
+        rad = u_rad ** 0.5 * light.radius
         self.stats.uniforms_drawn += 2 * N * h
         local = rad[:, None] * (np.cos(theta)[:, None] * light.x_hat + np.sin(theta)[:, None] * light.y_hat)
         L = (light.position + local) - tiled
@@ -254,11 +261,11 @@ class Oracle:
         edge = light.radius + light.tan_outer * np.abs(z)
         return rho, allowed, edge - allowed, rho <= edge
 
-    def _spot_light(self, light, P):
+    def _spot_light(self, light, P, light_index=0):
         h = P.shape[0]
         N = light.n_points
         rho, allowed, width, inside = self.beam_geometry(light, P)
-        i_d, i_s, Lu = self._disk_light(light, P[inside])
+        i_d, i_s, Lu = self._disk_light(light, P[inside], light_index)
         factor = self._ease(light.easing, rho[inside], allowed[inside], width[inside])[:, None]
         tot_d = np.zeros((h, 3))
         tot_s = np.zeros((h, 3))
@@ -283,25 +290,13 @@ class Oracle:
             surf += np.clip(k_s * i_s, 0, 1)
         return np.clip(surf, 0, 1)
 
-    # ------------------------------------------------------------ recursion
-    def _node(self, o, d, a, b, path):
+    # ------------------------------------------------------------ per-hit pieces
+    def _hit_record(self, o, d, t, sid):
+        """Geometry of a batch of hits (reference raytrace.py:53-99): hit point,
+        outward normal, inside flag, refraction normal, pulled-back point,
+        transmitted mask and direction, Fresnel reflectance."""
         p = self.p
-        n = o.shape[0]
-        call = NodeCall(a, b, n, path=path)
-        self.stats.calls.append(call)
-        if n < p.small_num:
-            return np.zeros((n, 3)) + self.bg
-
-        sid, t = self._nearest(o, d)
-        hit = sid != -1
-        h = int(hit.sum())
-        if h == 0:
-            return np.ones((n, 3)) * self.bg
-        call.hits = h
-        out = np.zeros((n, 3))
-        out[~hit] = self.bg
-        o, d, t, sid = o[hit], d[hit], t[hit][:, None], sid[hit]
-
+        h = o.shape[0]
         P = o + t * d
         nrm = P - self.centers[sid]
         nrm = nrm / np.linalg.norm(nrm, axis=-1, keepdims=True)
@@ -325,6 +320,67 @@ class Oracle:
         cos_f = np.where(n2 >= n1, _dot(d, N), _dot(T, N))
         R = R0 + (1 - R0) * (1 - cos_f) ** 5
         R[~trans] = 1
+        return P, nrm, inside, N, Pb, trans, T, R
+
+    def _lighting(self, sid, d, nrm, Pb):
+        """Clipped surface colour of a batch of hits under all lights plus ambient
+        (reference raytrace.py:136-152); also the in-beam count per light."""
+        h = d.shape[0]
+        surf = np.zeros((h, 3))
+        beams = []
+        for li, light in enumerate(self.s.lights):
+            if light.kind == F.LIGHT_POINT:
+                i_d, i_s, Lu = self._point_intensity(light, light.intensity, Pb, light.position - Pb)
+                vecs = Lu[None, :, :]
+                beams.append(0)
+            elif light.kind == F.LIGHT_DISK:
+                i_d, i_s, vecs = self._disk_light(light, Pb, li)
+                beams.append(0)
+            else:
+                i_d, i_s, vecs, nb = self._spot_light(light, Pb, li)
+                beams.append(nb)
+            surf += self._surface(sid, d, nrm, i_d, i_s, vecs)
+        surf += np.clip(self.mat[sid, F.MAT_AMBIENT:F.MAT_AMBIENT + 3] * self.s.ambient, 0, 1)
+        return np.clip(surf, 0, 1), beams
+
+    def _combine(self, sid, inside, R, surf, refr, refl):
+        """Weighted sum of surface, refraction and reflection colours of a batch of
+        hits (reference raytrace.py:155-168, before the final clip)."""
+        floor = np.where(inside, 0.0, self.mat[sid, F.MAT_REFLECTION])
+        A = (floor + (self.mat[sid, F.MAT_SMOOTHNESS] - floor) * R)[:, None]
+        tr = self.mat[sid, F.MAT_TRANSPARENCY][:, None]
+        surf = surf * ((1 - tr) * (1 - A))
+        refr = refr * (tr * (1 - A))
+        refl = refl * A
+        return surf + refr + refl
+
+    def _absorption(self, sid, Pb, T):
+        """RGB factor for light that crosses the sphere it just entered
+        (reference raytrace.py:117-119)."""
+        through = self._sphere_roots(sid, Pb, T, True)
+        coef = -self.mat[sid, F.MAT_ATTENUATION, None] * self.mat[sid, F.MAT_ABSORPTION:F.MAT_ABSORPTION + 3]
+        return np.exp(coef * through[:, None])
+
+    # ------------------------------------------------------------ recursion
+    def _node(self, o, d, a, b, path):
+        p = self.p
+        n = o.shape[0]
+        call = NodeCall(a, b, n, path=path)
+        self.stats.calls.append(call)
+        if n < p.small_num:
+            return np.zeros((n, 3)) + self.bg
+
+        sid, t = self._nearest(o, d)
+        hit = sid != -1
+        h = int(hit.sum())
+        if h == 0:
+            return np.ones((n, 3)) * self.bg
+        call.hits = h
+        out = np.zeros((n, 3))
+        out[~hit] = self.bg
+        o, d, t, sid = o[hit], d[hit], t[hit][:, None], sid[hit]
+
+        P, nrm, inside, N, Pb, trans, T, R = self._hit_record(o, d, t, sid)
 
         refr = np.zeros((h, 3))
         refl = np.zeros((h, 3))
@@ -332,10 +388,7 @@ class Oracle:
             refr[trans] = self._node(Pb[trans] + 2 * p.epsilon * N[trans], T[trans], a, b - 1, path + "t")
             entering = trans & ~inside
             if entering.any():
-                through = self._sphere_roots(sid[entering], Pb[entering], T[entering], True)
-                coef = -self.mat[sid[entering], F.MAT_ATTENUATION, None] * \
-                    self.mat[sid[entering], F.MAT_ABSORPTION:F.MAT_ABSORPTION + 3]
-                refr[entering] *= np.exp(coef * through[:, None])
+                refr[entering] *= self._absorption(sid[entering], Pb[entering], T[entering])
         if b != 0 and a != 0:
             tir = ~trans
             if tir.any():
@@ -343,31 +396,9 @@ class Oracle:
         if a != 0:
             refl = self._node(Pb, _reflect(d, -N), a - 1, b, path + "r")
 
-        surf = np.zeros((h, 3))
-        beams = []
-        for light in self.s.lights:
-            if light.kind == F.LIGHT_POINT:
-                i_d, i_s, Lu = self._point_intensity(light, light.intensity, Pb, light.position - Pb)
-                vecs = Lu[None, :, :]
-                beams.append(0)
-            elif light.kind == F.LIGHT_DISK:
-                i_d, i_s, vecs = self._disk_light(light, Pb)
-                beams.append(0)
-            else:
-                i_d, i_s, vecs, nb = self._spot_light(light, Pb)
-                beams.append(nb)
-            surf += self._surface(sid, d, nrm, i_d, i_s, vecs)
+        surf, beams = self._lighting(sid, d, nrm, Pb)
         call.beam = tuple(beams)
-        surf += np.clip(self.mat[sid, F.MAT_AMBIENT:F.MAT_AMBIENT + 3] * self.s.ambient, 0, 1)
-        surf = np.clip(surf, 0, 1)
-
-        floor = np.where(inside, 0.0, self.mat[sid, F.MAT_REFLECTION])
-        A = (floor + (self.mat[sid, F.MAT_SMOOTHNESS] - floor) * R)[:, None]
-        tr = self.mat[sid, F.MAT_TRANSPARENCY][:, None]
-        surf *= (1 - tr) * (1 - A)
-        refr *= tr * (1 - A)
-        refl *= A
-        out[hit] = surf + refr + refl
+        out[hit] = self._combine(sid, inside, R, surf, refr, refl)
         return np.clip(out, 0, 1)
 
 

@@ -140,7 +140,7 @@ def split_rows(height, world, band_rows, band_cost):
     per_row = np.repeat(cost / np.maximum(n_rows, 1), n_rows) + 1e-9 * max(cost.sum(), 1.0) / height
     cum = np.concatenate([[0.0], np.cumsum(per_row)])
     targets = cum[-1] * np.arange(1, world) / world
-    cuts = np.searchsorted(cum, targets, side="left")
+    cuts = np.searchsorted(cum, targets - 1e-7 * cum[-1], side="left")
     bounds = np.concatenate([[0], cuts, [height]]).astype(np.int64)
     if height >= world:
         for r in range(1, world + 1):                     # at least one row each, monotone
@@ -308,6 +308,48 @@ class ShardedRenderer:
         c = self.ctx.counters()
         return {"rays": int(c["rays"]), "hits": int(c["hits"]), "shaded_hits": int(c["shaded_hits"]),
                 "shaded_samples": int(c["shaded_samples"]), "spheres": self.flat.n_spheres}
+
+
+def raytrace_sharded(scene, params, comm, backend, rng=None):
+    """Render one frame split over the ranks of ``comm``; returns the whole
+    ``(height, width, 3)`` image on rank 0 and ``None`` on the other ranks.
+    Every rank must call it with the same scene and, for scenes with disk lights,
+    with identically seeded random streams."""
+    import torch
+    r = ShardedRenderer(scene, params, comm, backend)
+    r.choose_rows()
+    r.trace_checked()
+    r.draw_samples(rng)
+    r.shade()
+    W, H = r.params.width, r.params.height
+    r0, r1 = r.my_rows
+    tile = torch.from_numpy(np.ascontiguousarray(backend.read_image()[:(r1 - r0) * W]))
+    if comm.device is not None:
+        tile = tile.to(comm.device)
+    full = None
+    if comm.rank == 0:
+        full = torch.empty((H * W, 3), dtype=torch.float64, device=tile.device)
+        full[r0 * W:r1 * W] = tile
+    comm.gather_tiles(full, tile, r.bounds, W)
+    comm.barrier()
+    return full.cpu().numpy().reshape(H, W, 3) if comm.rank == 0 else None
+
+
+def raytrace(scene, *, params=None, device=None):
+    """``raytrace(scene)`` for a process group started by ``torch.distributed.run``
+    (one rank per GPU): rank 0 returns the image, the others ``None``."""
+    import torch
+    from . import _native
+    rank, world, group = init_group(None)
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(device)
+    comm = Comm(group, torch.device("cuda", device) if world > 1 else None)
+    ctx = _native.Context(device, torch.cuda.current_stream().cuda_stream)
+    try:
+        return raytrace_sharded(scene, params, comm, ctx)
+    finally:
+        ctx.close()
 
 
 # ----------------------------------------------------------------------------------------------

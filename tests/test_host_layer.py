@@ -1,0 +1,103 @@
+"""The host layer (scene classes, flattening) against parameters recorded from
+the reference's own classes (tests/golden/make_golden.py: scenes_flat, unit)."""
+import os
+
+import numpy as np
+import pytest
+
+from raytracing_amd import constants, materials, objects
+from raytracing_amd.flatten import (EASING_CODES, LIGHT_DISK, LIGHT_POINT, LIGHT_SPOT, flatten_scene)
+from raytracing_amd.Scenes import synthetic
+from raytracing_amd.Scenes.scenes import build_scene, scenes
+
+EXAMPLES = ["example_1", "example_2", "example_3", "example_4"]
+
+
+@pytest.mark.parametrize("name", EXAMPLES)
+def test_example_scenes_flatten_like_the_reference(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "scenes_flat.npz"))
+    f = flatten_scene(build_scene(name, 160, 90))
+    assert np.array_equal(f.sphere_geom, g[name + "_geom"])
+    assert np.array_equal(f.sphere_mat, g[name + "_mat"])
+    assert np.array_equal(f.ambient, g[name + "_ambient"])
+    assert np.array_equal(f.camera_position, g[name + "_camera"])
+    screen = np.concatenate([f.screen_position, f.screen_x, f.screen_y,
+                             [f.screen_width, f.screen_height, f.pixels_x, f.pixels_y]])
+    assert np.array_equal(screen, g[name + "_screen"])
+    l = f.lights[0]
+    assert np.array_equal(np.concatenate([[l.kind], l.position, [l.intensity, l.radius, l.n_points]]), g[name + "_light"])
+
+
+def test_camera_frames_match_the_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unit_kats.npz"))
+    for i, name in enumerate(EXAMPLES):
+        s = build_scene(name, 160, 90)
+        cam, scr = s.camera, s.screen
+        frame = np.concatenate([cam.position, cam.viewing_direction, cam.y_vector, scr.position,
+                                scr.x_vector, scr.y_vector, [scr.width, scr.height]])
+        assert np.array_equal(frame, g["screen_frames"][i])
+
+
+def test_camera_normalises_the_callers_direction_in_place():
+    v = np.array([3.0, 0.0, 4.0])
+    objects.Camera(viewing_direction=v)
+    np.testing.assert_allclose(v, [0.6, 0.0, 0.8])
+
+
+def test_defaults_follow_the_reference():
+    s = objects.Sphere()
+    assert list(s.position) == [4, 0, 0] and s.radius == 1.0
+    assert objects.Sphere().material is s.material                      # shared default material
+    m = materials.Material()
+    assert (m.diffuse_coefficient, m.specular_coefficient, m.shininess) == (0.8, 0.3, 100)
+    assert (m.reflection_coefficient, m.transparency_coefficient, m.refractive_index, m.smoothness,
+            m.attenuation_coefficient) == (0, 0, 1, 0, 0.1)
+    assert np.array_equal(m.ambient_color, constants.YELLOW)
+    assert np.array_equal(m.absorption_color, [0, 0, 1])
+    assert np.array_equal(materials.Material(diffuse_color=constants.WHITE).absorption_color, constants.WHITE)
+    assert np.array_equal(materials.Material(diffuse_color=constants.GREY).absorption_color, [1, 1, 1])
+    p = objects.PointSource()
+    assert list(p.position) == [4, 0, 20] and p.intensity == 15
+    d = objects.DiskSource()
+    assert (d.radius, d.n_points) == (3.0, 30) and list(d.normal_vector) == [0, 0, -1]
+    sp = objects.DirectionalDiskSource(angle=30)
+    assert sp.n_points == 30 and sp.easing_mode == "quadratic"
+    assert sp.angle == 30 * np.pi / 180 and sp.fall_off_angle == 20 * np.pi / 180
+    assert set(scenes) == set(EXAMPLES)
+    assert (constants.MAX_REFLECTION_DEPTH, constants.MAX_REFRACTION_DEPTH, constants.SMALL_NUM) == (3, 5, 3)
+    assert constants.EPSILON == 1e-5 and np.array_equal(constants.BACKGROUND_COLOR, [0.251, 0.624, 0.769])
+
+
+def test_light_kinds_and_disk_frames():
+    f = flatten_scene(synthetic.spotlight_scene("cubic", 64, 128, 72))
+    l = f.lights[0]
+    assert l.kind == LIGHT_SPOT and l.easing == EASING_CODES["cubic"] and l.n_points == 64
+    assert np.array_equal(l.x_hat, [0, -1, 0]) and np.array_equal(l.y_hat, [-1, 0, 0])   # not normalised, as built
+    assert l.tan_angle == np.tan(20 * np.pi / 180) and l.tan_outer == np.tan(40 * np.pi / 180)
+    f4 = flatten_scene(build_scene("example_4", 32, 18))
+    assert f4.lights[0].kind == LIGHT_DISK and f4.has_sampled_lights
+    assert flatten_scene(build_scene("example_1", 32, 18)).lights[0].kind == LIGHT_POINT
+    odd = objects.DirectionalDiskSource(easing_mode="bouncy")
+    scene = build_scene("example_1", 32, 18)
+    scene.light_sources = [odd]
+    assert flatten_scene(scene).lights[0].easing == 0          # unknown mode behaves like "none"
+    side = objects.DiskSource()
+    side.normal_vector = np.array([1.0, 0.0, 0.0])
+    scene.light_sources = [side]
+    l = flatten_scene(scene).lights[0]
+    assert np.array_equal(l.x_hat, np.cross([1.0, 0, 0], [0, 1.0, 0]))
+
+
+def test_many_spheres_scene_is_reproducible():
+    a = flatten_scene(synthetic.many_spheres_scene(257, 64, 36))
+    b = flatten_scene(synthetic.many_spheres_scene(257, 64, 36))
+    assert a.n_spheres == 257 and np.array_equal(a.sphere_geom, b.sphere_geom)
+    assert a.sphere_geom[0, 3] == 1e7 and a.sphere_geom[1:, 3].max() <= 0.6
+    assert 0.6 < (a.sphere_mat[1:, 11] > 0).mean() < 0.8      # about 70 % glass
+
+
+def test_flatten_rejects_oversized_scenes():
+    scene = build_scene("example_1", 32, 18)
+    scene.light_sources = [objects.PointSource()] * 9
+    with pytest.raises(ValueError):
+        flatten_scene(scene)
