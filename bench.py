@@ -144,7 +144,7 @@ def main():
     local = [job.local_stats() for job in jobs]      # this rank's share, what its kernels executed
     flops = {
         "trace": sum(F_ISECT * s["rays"] * s["spheres"] + F_HIT * s["hits"] for s in local),
-        "shade": sum((F_LIGHT + F_SHADOW * s["spheres"]) * s["shaded_samples"] for s in local),
+        "surface": sum((F_LIGHT + F_SHADOW * s["spheres"]) * s["shaded_samples"] for s in local),
     }
     roofline = None
     if dominant in flops and prof[dominant]["launches"]:

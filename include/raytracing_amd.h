@@ -28,7 +28,7 @@ extern "C" {
 #define RT_MAX_LIGHTS 8
 #define RT_MAX_SPHERES 65535
 #define RT_MAT_WIDTH 18
-#define RT_NUM_COUNTERS (4 + RT_MAX_LIGHTS)
+#define RT_NUM_COUNTERS (5 + RT_MAX_LIGHTS)
 
 #define RT_OK 0
 #define RT_ERR_INVALID (-1)   /* bad argument / unsupported scene            */
@@ -110,6 +110,8 @@ typedef struct RtCounters {
     int64_t shaded_hits;     /* hits whose surface colour was evaluated by rt_shade (hits
                                 with zero weight in the pixel are skipped)             */
     int64_t shaded_samples;  /* light samples evaluated for them = shadow rays cast    */
+    int64_t fallback_samples;/* disk-light samples the float32 evaluation could not
+                                certify and re-evaluated in float64 (mixed precision)  */
     int64_t arena_rays_used; /* ray slots used, including tile padding                 */
     int64_t arena_capacity;  /* ray slots allocated                                    */
     int32_t n_nodes;         /* nodes of the static ray tree                           */
@@ -119,7 +121,8 @@ typedef struct RtCounters {
 } RtCounters;
 
 /* Accumulated device time per kernel kind, filled when profiling is on. */
-enum { RT_K_TRACE = 0, RT_K_SCAN = 1, RT_K_LINK = 2, RT_K_SHADE = 3, RT_K_INIT = 4, RT_K_COUNT = 5 };
+enum { RT_K_TRACE = 0, RT_K_SCAN = 1, RT_K_LINK = 2, RT_K_SURFACE = 3, RT_K_COMBINE = 4, RT_K_INIT = 5,
+       RT_K_COUNT = 6 };
 typedef struct RtProfile {
     double ms[RT_K_COUNT];
     int64_t launches[RT_K_COUNT];
@@ -192,6 +195,16 @@ int rt_get_node_counts(RtContext *ctx, int64_t *batch, int64_t *hits, int64_t *b
  * context's (in-beam) hit count, N = n_points - and the total length. */
 int rt_set_sample_layout(RtContext *ctx, const int64_t *offsets /* [n_nodes][RT_MAX_LIGHTS] */, int64_t total);
 int rt_upload_samples(RtContext *ctx, int64_t dst_offset, const double *u, int64_t n);
+
+/* Arithmetic of the disk-light sample loop in rt_shade.
+ * RT_PRECISION_F64: every sample in float64, the reference's operations.
+ * RT_PRECISION_MIXED (default): samples in float32 with a rigorous error bound on
+ * every shadow-ray discriminant; a sample with a decision inside its bound is
+ * re-evaluated in float64, so shadow decisions are those of the float64 path and
+ * colours differ by float32 rounding of continuous terms only (< 1e-5).
+ * Geometry (hits, child rays, counts) is float64 in both modes. */
+enum { RT_PRECISION_F64 = 0, RT_PRECISION_MIXED = 1 };
+int rt_set_precision(RtContext *ctx, int32_t mode);
 
 /* Lighting, shading and bottom-up colour combination (reference
  * raytrace.py:135-170 and objects.py:94-235), deepest level first.  Leaves the

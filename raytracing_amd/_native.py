@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "_rt_hip.so")
 RT_MAX_LIGHTS = 8
 RT_MAT_WIDTH = 18
 RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_OVERFLOW, RT_ERR_STATE = 0, -1, -2, -3, -4
-KERNEL_KINDS = ("trace", "scan", "link", "shade", "init")
+KERNEL_KINDS = ("trace", "scan", "link", "surface", "combine", "init")
 
 
 class RtError(RuntimeError):
@@ -58,13 +58,13 @@ class RtParams(C.Structure):
 
 class RtCounters(C.Structure):
     _fields_ = [("pixels", C.c_int64), ("rays", C.c_int64), ("hits", C.c_int64),
-                ("shaded_hits", C.c_int64), ("shaded_samples", C.c_int64),
+                ("shaded_hits", C.c_int64), ("shaded_samples", C.c_int64), ("fallback_samples", C.c_int64),
                 ("arena_rays_used", C.c_int64), ("arena_capacity", C.c_int64),
                 ("n_nodes", C.c_int32), ("n_levels", C.c_int32), ("overflow", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RtProfile(C.Structure):
-    _fields_ = [("ms", C.c_double * 5), ("launches", C.c_int64 * 5)]
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int64 * 6)]
 
 
 _P = C.c_void_p
@@ -88,6 +88,7 @@ SIGNATURES = {
     "rt_get_node_counts": (C.c_int, [_P, _I64P, _I64P, _I64P]),
     "rt_set_sample_layout": (C.c_int, [_P, _I64P, C.c_int64]),
     "rt_upload_samples": (C.c_int, [_P, C.c_int64, _F64P, C.c_int64]),
+    "rt_set_precision": (C.c_int, [_P, C.c_int32]),
     "rt_shade": (C.c_int, [_P]),
     "rt_set_output": (C.c_int, [_P, _P]),
     "rt_read_image": (C.c_int, [_P, _F64P]),
@@ -267,6 +268,10 @@ class Context:
     def upload_samples(self, dst_offset, u):
         u = _f64(u).reshape(-1)
         _check(self.lib.rt_upload_samples(self._h, int(dst_offset), _ptr(u, C.c_double), u.size))
+
+    def set_precision(self, mode):
+        """"f64" or "mixed" (see rt_set_precision in the header)."""
+        _check(self.lib.rt_set_precision(self._h, {"f64": 0, "mixed": 1}[mode]))
 
     def shade(self):
         _check(self.lib.rt_shade(self._h))

@@ -107,9 +107,15 @@ struct RtContext {
     DevBuf<int32_t> node_a, node_b, node_branch, node_child, level_start;
     DevBuf<int32_t> node_n, node_nglobal, node_hits, node_beam, node_tile0, node_ntiles, lvl_ntiles, lvl_tilebase, flags;
     DevBuf<uint32_t> node_start, node_pre, tile_run, blk_tot;
-    DevBuf<double> px, py, pz, dx, dy, dz, nx, ny, nz, A, dist, cr, cg, cb;
-    DevBuf<uint32_t> info, link;
-    DevBuf<double> X, Y, samples, image;
+    DevBuf<double> px, py, pz, dx, dy, dz, A, dist, cr, cg, cb;
+    DevBuf<uint32_t> info, link, list_ray, redo_list, list_j[1 + RT_MAX_LIGHTS];
+    DevBuf<uint16_t> list_node;
+    DevBuf<int32_t> lvl_shade_base;
+    uint32_t spot_mask = 0;
+    bool disk_lights = false;
+    DevBuf<double> X, Y, packed, staging, image;
+    int64_t pack_base[RT_MAX_LIGHTS] = {0};
+    int64_t pack_E = 0;
     DevBuf<int64_t> sample_off;
     DevBuf<unsigned long long> work;
     double* user_image = nullptr;
@@ -120,6 +126,7 @@ struct RtContext {
     int64_t arena_rays = 0;
     int64_t sample_total = 0;
 
+    int precision = RT_PRECISION_MIXED;
     bool profiling = false;
     struct Stamp { int kind; hipEvent_t t0, t1; };
     std::vector<Stamp> stamps;
@@ -135,12 +142,16 @@ struct RtContext {
         D.node_tile0 = node_tile0.p; D.node_ntiles = node_ntiles.p; D.node_start = node_start.p; D.node_pre = node_pre.p;
         D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p;
         D.flags = flags.p; D.work = work.p;
-        D.px = px.p; D.py = py.p; D.pz = pz.p; D.dx = dx.p; D.dy = dy.p; D.dz = dz.p; D.nx = nx.p; D.ny = ny.p; D.nz = nz.p; D.A = A.p; D.dist = dist.p;
+        D.px = px.p; D.py = py.p; D.pz = pz.p; D.dx = dx.p; D.dy = dy.p; D.dz = dz.p; D.A = A.p; D.dist = dist.p;
         D.info = info.p; D.link = link.p; D.cr = cr.p; D.cg = cg.p; D.cb = cb.p;
         D.cap_tiles = (uint32_t)(arena_rays / TILE);
+        D.lvl_shade_base = lvl_shade_base.p; D.list_ray = list_ray.p; D.list_node = list_node.p; D.redo_list = redo_list.p;
+        for (int l = 0; l <= RT_MAX_LIGHTS; ++l) D.list_j[l] = list_j[l].n ? list_j[l].p : nullptr;
+        D.spot_mask = spot_mask;
         D.X = explicit_xy ? X.p : nullptr; D.Y = explicit_xy ? Y.p : nullptr;
         D.row0 = row0; D.npix = (int32_t)npix;
-        D.samples = samples.p; D.sample_off = sample_off.p;
+        D.packed = packed.p; D.pack_E = pack_E; D.sample_off = sample_off.p;
+        for (int l = 0; l < RT_MAX_LIGHTS; ++l) D.pack_base[l] = pack_base[l];
         D.image = user_image ? user_image : image.p;
         return D;
     }
@@ -195,11 +206,9 @@ int launch_level(RtContext* ctx, int level) {
     ctx->begin(RT_K_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, D, level);
     ctx->end();
-    if (level + 1 < D.n_levels) {
-        ctx->begin(RT_K_LINK);
-        hipLaunchKernelGGL(k_link, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
-        ctx->end();
-    }
+    ctx->begin(RT_K_LINK);
+    hipLaunchKernelGGL(k_link, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
+    ctx->end();
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -269,9 +278,11 @@ void rt_destroy(RtContext* ctx) {
     ctx->node_beam.release(); ctx->node_tile0.release(); ctx->node_ntiles.release(); ctx->lvl_ntiles.release();
     ctx->lvl_tilebase.release(); ctx->flags.release(); ctx->node_start.release(); ctx->node_pre.release();
     ctx->tile_run.release(); ctx->blk_tot.release();
-    ctx->px.release(); ctx->py.release(); ctx->pz.release(); ctx->dx.release(); ctx->dy.release(); ctx->dz.release(); ctx->nx.release(); ctx->ny.release(); ctx->nz.release();
+    ctx->px.release(); ctx->py.release(); ctx->pz.release(); ctx->dx.release(); ctx->dy.release(); ctx->dz.release();
     ctx->A.release(); ctx->dist.release(); ctx->cr.release(); ctx->cg.release(); ctx->cb.release();
-    ctx->info.release(); ctx->link.release(); ctx->X.release(); ctx->Y.release(); ctx->samples.release();
+    ctx->info.release(); ctx->link.release(); ctx->list_ray.release(); ctx->redo_list.release(); ctx->list_node.release(); ctx->lvl_shade_base.release();
+    for (auto& b : ctx->list_j) b.release();
+    ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->staging.release();
     ctx->image.release(); ctx->sample_off.release(); ctx->work.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -296,13 +307,15 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
             return fail(RT_ERR_INVALID, "ray tree level %d is wider than %d nodes", l, MAX_LEVEL_NODES);
 
     SceneConst sc{};
-    bool sampled = false;
+    bool sampled = false, disk = false;
+    uint32_t spot_mask = 0;
     for (int l = 0; l < scene->n_lights; ++l) {
         const RtLight& L = scene->lights[l];
         if (L.kind < RT_LIGHT_POINT || L.kind > RT_LIGHT_SPOT) return fail(RT_ERR_INVALID, "light %d: unknown kind %d", l, L.kind);
         if (L.kind != RT_LIGHT_POINT) {
             if (L.n_points < 1) return fail(RT_ERR_INVALID, "light %d: n_points must be >= 1", l);
             sampled = true;
+            if (L.kind == RT_LIGHT_SPOT) spot_mask |= 1u << l; else disk = true;
         }
         sc.lights[l] = L;
     }
@@ -339,6 +352,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     HIP_TRY(ctx->node_beam.ensure(K * RT_MAX_LIGHTS)); HIP_TRY(ctx->node_tile0.ensure(K)); HIP_TRY(ctx->node_ntiles.ensure(K));
     HIP_TRY(ctx->node_start.ensure(K)); HIP_TRY(ctx->node_pre.ensure(K * NCNT));
     HIP_TRY(ctx->lvl_ntiles.ensure(tree.n_levels())); HIP_TRY(ctx->lvl_tilebase.ensure(tree.n_levels()));
+    HIP_TRY(ctx->lvl_shade_base.ensure(tree.n_levels() + 1));
     HIP_TRY(ctx->blk_tot.ensure((size_t)tree.n_levels() * NB * NCNT));
     HIP_TRY(ctx->flags.ensure(4));
     HIP_TRY(ctx->work.ensure(4));
@@ -349,6 +363,9 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     ctx->params = *params;
     ctx->S = (int)S;
     ctx->sampled_lights = sampled;
+    ctx->disk_lights = disk;
+    ctx->spot_mask = spot_mask;
+    for (auto& b : ctx->list_j) b.release();   // sized per frame for the lights of this scene
     ctx->have_scene = true;
     ctx->frame_begun = ctx->geometry_done = ctx->layout_set = ctx->shaded = false;
     return RT_OK;
@@ -376,10 +393,16 @@ int rt_begin_frame(RtContext* ctx, int32_t row0, int32_t n_rows, const double* X
 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const size_t R = (size_t)arena_rays;
-    DevBuf<double>* dbl[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->dx, &ctx->dy, &ctx->dz, &ctx->nx, &ctx->ny, &ctx->nz, &ctx->A, &ctx->dist, &ctx->cr, &ctx->cg, &ctx->cb};
+    DevBuf<double>* dbl[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->dx, &ctx->dy, &ctx->dz, &ctx->A, &ctx->dist, &ctx->cr, &ctx->cg, &ctx->cb};
     for (auto* buf : dbl) HIP_TRY(buf->ensure(R));
     HIP_TRY(ctx->info.ensure(R));
     HIP_TRY(ctx->link.ensure(R));
+    HIP_TRY(ctx->list_ray.ensure(R));
+    HIP_TRY(ctx->list_node.ensure(R));
+    if (ctx->sampled_lights) HIP_TRY(ctx->redo_list.ensure(R));
+    if (ctx->disk_lights) HIP_TRY(ctx->list_j[0].ensure(R));
+    for (int l = 0; l < RT_MAX_LIGHTS; ++l)
+        if ((ctx->spot_mask >> l) & 1u) HIP_TRY(ctx->list_j[1 + l].ensure(R));
     HIP_TRY(ctx->tile_run.ensure(R / TILE * NCNT));
     HIP_TRY(ctx->image.ensure((size_t)npix * 3));
     ctx->explicit_xy = X != nullptr;
@@ -482,9 +505,20 @@ int rt_set_sample_layout(RtContext* ctx, const int64_t* offsets, int64_t total) 
     if (!ctx->geometry_done) return fail(RT_ERR_STATE, "geometry phase not finished");
     if (!offsets || total < 0) return fail(RT_ERR_INVALID, "bad sample layout");
     const size_t n = (size_t)ctx->tree.n_nodes() * RT_MAX_LIGHTS;
+    // the packed buffer has one slot per (sampled light, sample, shading-list entry)
+    int32_t entries = 0, flag = 0;
+    HIP_TRY(hipMemcpyAsync(&entries, ctx->lvl_shade_base.p + ctx->tree.n_levels(), 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx->samples.ensure((size_t)total));
+    if (flag) return fail(RT_ERR_OVERFLOW, "ray arena of %lld rays is too small for this frame", (long long)ctx->arena_rays);
+    int64_t slots = 0;
+    for (int l = 0; l < ctx->sc_host.n_lights; ++l) {
+        ctx->pack_base[l] = slots;
+        if (ctx->sc_host.lights[l].kind != RT_LIGHT_POINT) slots += (int64_t)ctx->sc_host.lights[l].n_points * entries;
+    }
+    HIP_TRY(ctx->packed.ensure((size_t)slots * 2));
     HIP_TRY(hipMemcpy(ctx->sample_off.p, offsets, n * sizeof(int64_t), hipMemcpyHostToDevice));
+    ctx->pack_E = entries;
     ctx->sample_total = total;
     ctx->layout_set = true;
     return RT_OK;
@@ -496,7 +530,16 @@ int rt_upload_samples(RtContext* ctx, int64_t dst_offset, const double* u, int64
     if (n < 0 || dst_offset < 0 || dst_offset + n > ctx->sample_total) return fail(RT_ERR_INVALID, "sample range out of bounds");
     if (n == 0) return RT_OK;
     if (!u) return fail(RT_ERR_INVALID, "u is null");
-    HIP_TRY(hipMemcpy(ctx->samples.p + dst_offset, u, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    // stage the piece of the stream, then scatter it into the packed layout
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx->staging.ensure((size_t)n));
+    HIP_TRY(hipMemcpyAsync(ctx->staging.p, u, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->pack_E > 0) {
+        const int64_t blocks = std::min<int64_t>((ctx->pack_E + TILE - 1) / TILE, 4 * NB);
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(TILE), 0, ctx->stream, ctx->dev(), ctx->staging.p, dst_offset, n);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller
     return RT_OK;
 }
 
@@ -507,10 +550,16 @@ int rt_shade(RtContext* ctx) {
         return fail(RT_ERR_STATE, "the scene has disk lights: upload their samples before shading");
     const Dev D = ctx->dev();
     const bool lds = ctx->S <= SHADE_LDS_SPHERES;
+    const bool mixed = ctx->precision == RT_PRECISION_MIXED && ctx->sampled_lights && ctx->S <= SREG;
+    ctx->begin(RT_K_SURFACE);
+    if (lds && mixed) hipLaunchKernelGGL((k_surface<true, true>), dim3(NB), dim3(TILE), 0, ctx->stream, D);
+    else if (lds) hipLaunchKernelGGL((k_surface<true, false>), dim3(NB), dim3(TILE), 0, ctx->stream, D);
+    else hipLaunchKernelGGL((k_surface<false, false>), dim3(NB), dim3(TILE), 0, ctx->stream, D);
+    if (mixed) hipLaunchKernelGGL((k_surface_redo<true>), dim3(64), dim3(TILE), 0, ctx->stream, D);
+    ctx->end();
     for (int level = D.n_levels - 1; level >= 0; --level) {
-        ctx->begin(RT_K_SHADE);
-        if (lds) hipLaunchKernelGGL(k_shade<true>, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
-        else hipLaunchKernelGGL(k_shade<false>, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
+        ctx->begin(RT_K_COMBINE);
+        hipLaunchKernelGGL(k_combine, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
         ctx->end();
     }
     HIP_TRY(hipGetLastError());
@@ -522,6 +571,13 @@ int rt_set_output(RtContext* ctx, void* device_rgb) {
     if (int rc = use_device(ctx)) return rc;
     if (!ctx->frame_begun) return fail(RT_ERR_STATE, "rt_begin_frame has not been called");
     ctx->user_image = (double*)device_rgb;
+    return RT_OK;
+}
+
+int rt_set_precision(RtContext* ctx, int32_t mode) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    if (mode != RT_PRECISION_F64 && mode != RT_PRECISION_MIXED) return fail(RT_ERR_INVALID, "unknown precision mode %d", mode);
+    ctx->precision = mode;
     return RT_OK;
 }
 
@@ -558,7 +614,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     const int K = ctx->tree.n_nodes(), Lv = ctx->tree.n_levels();
     std::vector<int32_t> n(K), ng(K), h(K), nt(Lv), tb(Lv);
     int32_t flag = 0;
-    unsigned long long work[2] = {0, 0};
+    unsigned long long work[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(work, ctx->work.p, sizeof work, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(n.data(), ctx->node_n.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ng.data(), ctx->node_nglobal.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -575,6 +631,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     }
     out->shaded_hits = (int64_t)work[0];
     out->shaded_samples = (int64_t)work[1];
+    out->fallback_samples = (int64_t)work[2];
     out->arena_rays_used = (int64_t)(tb[Lv - 1] + nt[Lv - 1]) * TILE;
     out->arena_capacity = ctx->arena_rays;
     out->n_nodes = K;

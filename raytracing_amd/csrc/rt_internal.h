@@ -9,7 +9,7 @@ namespace rt {
 
 constexpr int TILE = 256;             // rays per tile = threads per workgroup
 constexpr int NB = 2048;              // workgroups per level launch (256 CUs x 8)
-constexpr int NCNT = RT_NUM_COUNTERS; // per-tile counters: 3 child kinds, hits, in-beam per light
+constexpr int NCNT = RT_NUM_COUNTERS; // per-tile counters: 3 child kinds, hits, in-beam per light, shade items
 constexpr int MAX_LEVELS = 32;
 constexpr int MAX_LEVEL_NODES = 1024; // widest level of the static ray tree we accept
 constexpr int MAX_NODES = 65536;
@@ -17,7 +17,7 @@ constexpr int SPH_CHUNK = 1024;       // spheres staged in LDS per pass of the n
 constexpr int SHADE_LDS_SPHERES = 512;
 
 // counters
-enum { C_T = 0, C_I = 1, C_R = 2, C_HIT = 3, C_BEAM0 = 4 };
+enum { C_T = 0, C_I = 1, C_R = 2, C_HIT = 3, C_BEAM0 = 4, C_SHADE = 4 + RT_MAX_LIGHTS };
 
 // bits of the per-ray info word
 constexpr uint32_t I_SID_MASK = 0xFFFFu;
@@ -26,8 +26,8 @@ constexpr uint32_t I_INSIDE = 1u << 17;
 constexpr uint32_t I_CHILD_T = 1u << 18;  // spawned a transmitted ray
 constexpr uint32_t I_CHILD_I = 1u << 19;  // spawned a total-internal-reflection ray
 constexpr uint32_t I_CHILD_R = 1u << 20;  // spawned a mirror-reflection ray
-constexpr uint32_t I_LIVE = 1u << 21;     // the ray's colour reaches the pixel with non-zero weight
-constexpr uint32_t I_LIVE_TI = 1u << 22;  // ... and so does its refraction slot
+constexpr uint32_t I_SHADE = 1u << 21;    // the hit's surface colour reaches the pixel with non-zero weight
+constexpr uint32_t I_LIVE_TI = 1u << 22;  // the ray's refraction slot reaches the pixel with non-zero weight
 constexpr uint32_t I_LIVE_R = 1u << 23;   // ... and so does its reflection slot
 constexpr int I_BEAM_SHIFT = 24;          // bit 24 + l: hit lies inside spotlight l's beam
 
@@ -72,26 +72,36 @@ struct Dev {
     int32_t* lvl_tilebase;  // [n_levels] first tile of the level in the arena
     uint32_t* tile_run;     // [tiles][NCNT] running counter value inside the producing workgroup
     uint32_t* blk_tot;      // [n_levels][NB][NCNT] per-workgroup totals, turned into prefixes by k_scan
-    int32_t* flags;         // [0] overflow
+    int32_t* flags;         // [0] overflow, [1] entries queued for float64 re-evaluation
     unsigned long long* work;  // [0] hits shaded, [1] light samples evaluated (cleared by k_init)
     // ray arena (structure of arrays, one slot per ray)
-    double *px, *py, *pz;   // pulled-back hit point
+    double *px, *py, *pz;   // hit point
     double *dx, *dy, *dz;   // ray direction
-    double *nx, *ny, *nz;   // surface normal facing along the ray (the reference's refraction normal)
     double *A;              // reflected fraction
     double *dist;           // path length inside the entered sphere (0: no attenuation)
     uint32_t* info;
     uint32_t* link;         // arena index of the parent ray
-    double *cr, *cg, *cb;   // ray colour
+    double *cr, *cg, *cb;   // surface colour (after k_surface), then ray colour (after k_combine)
     uint32_t cap_tiles;
+    // dense list of the hits that need lighting, all levels one after the other
+    int32_t* lvl_shade_base;   // [n_levels + 1] first list entry of each level; the last one is the total
+    uint32_t* list_ray;        // arena index of the hit
+    uint16_t* list_node;       // its tree node
+    uint32_t* list_j[1 + RT_MAX_LIGHTS];  // [0] rank among the node's hits (disk lights), [1 + l] rank among
+                                          // the node's hits inside spotlight l's beam; NULL when unused
+    uint32_t spot_mask;        // bit l: light l is a spotlight
+    uint32_t* redo_list;       // shading-list entries whose float32 lighting could not be certified
     // level-0 pixels
     const double* X;
     const double* Y;        // NULL: whole rows starting at row0
     int32_t row0;
     int32_t npix;
-    // samples
-    const double* samples;
-    const int64_t* sample_off;  // [K][RT_MAX_LIGHTS]
+    // disk-light samples, packed per shading-list entry: for light l, sample s of entry e is the
+    // pair packed[2 * (pack_base[l] + s * pack_E + e)] = (angle uniform, radius uniform)
+    double* packed;
+    int64_t pack_base[RT_MAX_LIGHTS];
+    int64_t pack_E;             // entries of the shading list when the samples were packed
+    const int64_t* sample_off;  // [K][RT_MAX_LIGHTS] offset of each (node, light) block in the caller's stream
     // output
     double* image;  // [npix][3]
 };

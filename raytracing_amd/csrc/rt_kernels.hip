@@ -1,7 +1,7 @@
 // HIP kernels of the level-synchronous wavefront ray tracer (gfx950, wave64).
 //
 // One frame is:  k_init, then for every bounce level  k_trace -> k_scan -> k_link,
-// then from the deepest level upwards  k_shade.
+// then  k_surface  once, then from the deepest level upwards  k_combine.
 //
 //  * A level's rays live in the arena in tiles of 256, grouped by tree node
 //    (a node = all rays that followed the same branch sequence, the batch of one
@@ -9,12 +9,24 @@
 //    ascending pixel order, as boolean-mask selection keeps them in the reference.
 //  * k_trace derives each ray from its parent's hit record, finds the nearest
 //    sphere and stores the hit record; it counts, per tile, the children each
-//    branch will get.  k_scan turns the counts into node sizes and slots,
-//    k_link writes for every child slot the index of its parent (ordered
-//    compaction with wave ballots), so the next level's rays are dense.
-//  * k_shade evaluates lights and combines a ray's surface colour with its
-//    children's colours (bottom-up, exactly the reference's return path).
+//    branch will get, the hits, the hits inside each spotlight's beam and the
+//    hits whose surface colour will be needed.
+//  * k_scan turns the counts into node sizes and slots.
+//  * k_link is the ordered compaction (wave ballots + prefix): every child slot of
+//    the next level learns its parent, and every hit that needs lighting is
+//    appended to one dense list together with its rank inside its node.
+//  * k_surface evaluates the lights for the dense list (all levels in one launch,
+//    full waves whatever the fraction of rays that matter).
+//  * k_combine adds a ray's surface colour and its children's colours (bottom-up,
+//    the reference's return path).
+//
+// Compiled with -ffp-contract=off: the geometry follows the reference's rounding
+// order operation by operation; only explicit fma() calls fuse.
 #include "rt_internal.h"
+
+#ifndef RT_MIXED_WAVES
+#define RT_MIXED_WAVES 2   // waves per SIMD requested for the mixed-precision surface kernel
+#endif
 
 namespace rt {
 
@@ -57,12 +69,16 @@ __device__ __forceinline__ unsigned gscan(const Dev& D, int level, int tbase, in
     return D.blk_tot[((size_t)level * NB + t / q) * NCNT + c] + D.tile_run[(size_t)(tbase + t) * NCNT + c];
 }
 
+// Bit of the info word that counter c counts.
+__device__ __forceinline__ int counter_bit(int c) {
+    return c < 3 ? 18 + c : (c == C_HIT ? 16 : (c == C_SHADE ? 21 : I_BEAM_SHIFT + (c - C_BEAM0)));
+}
+
 // Roots of |o + t d - c|^2 = r^2 for unit d; returns false if there is none; lo <= hi.
 //
 // Every hit / miss decision of the frame hangs on the sign of this discriminant, and
 // scenes do contain rays that are exactly tangent to a sphere, so the arithmetic
-// follows reference objects.py:60-66 and :242-251 operation by operation (this file is
-// compiled with -ffp-contract=off; only the explicit fma() calls fuse):
+// follows reference objects.py:60-66 and :242-251 operation by operation:
 //   B = 2 (sum(d*o) - dot(d, c)),  C = sum((c-o)^2) - r^2,  disc = B^2 - 4C,
 //   roots -B/2 +- sqrt(disc)/2.
 // sum() adds left to right; dot(d, c) is the BLAS product of the NumPy build the
@@ -84,6 +100,22 @@ __device__ __forceinline__ bool sphere_roots(V3 o, V3 d, double d_o, double cx, 
     return true;
 }
 
+// What is recomputed from a stored hit record (hit point P, sphere, inside flag)
+// with exactly the operations k_trace used when it made the record
+// (reference raytrace.py:60-62, :86-89).
+struct Surface {
+    V3 n;   // outward unit normal
+    V3 N;   // normal facing along the ray
+    V3 Pb;  // hit point pulled back by epsilon to the side the ray came from
+};
+__device__ __forceinline__ Surface surface_at(V3 P, const double* g, bool inside, double eps) {
+    Surface s;
+    s.n = normalize(P - ld3(g));
+    s.N = inside ? s.n : -s.n;
+    s.Pb = P - eps * s.N;
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ void k_init(Dev D) {
     const int tid = threadIdx.x;
@@ -101,12 +133,15 @@ __global__ void k_init(Dev D) {
         D.lvl_ntiles[l] = 0;
         D.lvl_tilebase[l] = 0;
     }
+    for (int l = tid; l <= D.n_levels; l += blockDim.x) D.lvl_shade_base[l] = 0;
     __syncthreads();
     if (tid == 0) {
         int nt = (D.npix + TILE - 1) / TILE;
         D.flags[0] = 0;
+        D.flags[1] = 0;
         D.work[0] = 0;
         D.work[1] = 0;
+        D.work[2] = 0;
         if ((uint32_t)nt > D.cap_tiles) {
             D.flags[0] = 1;
             nt = 0;
@@ -153,11 +188,11 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
         const int k = k0 + find_node(s_tile_end, nn, t);
         const int first = (t - D.node_tile0[k]) * TILE;
         const int cnt = min(TILE, D.node_n[k] - first);
-        const bool dead = D.node_nglobal[k] < sc.small_num;
+        const bool dead = D.node_nglobal[k] < sc.small_num;   // reference raytrace.py:26-27
         const int a = D.node_a[k], b = D.node_b[k];
         const uint32_t idx = (uint32_t)(tbase + t) * TILE + tid;
         const bool valid = tid < cnt;
-        bool active = valid && !dead;
+        const bool active = valid && !dead;
 
         // ---- derive the ray ------------------------------------------------------------------
         V3 o = {0, 0, 0}, d = {1, 0, 0};
@@ -179,26 +214,26 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
                 const uint32_t pinfo = D.info[p];
                 const int psid = pinfo & I_SID_MASK;
                 const bool pinside = pinfo & I_INSIDE;
-                V3 Pb = {D.px[p], D.py[p], D.pz[p]};
+                V3 P = {D.px[p], D.py[p], D.pz[p]};
                 V3 pd = {D.dx[p], D.dy[p], D.dz[p]};
-                V3 N = {D.nx[p], D.ny[p], D.nz[p]};
-                double cosi = dot(N, pd);
+                const Surface sf = surface_at(P, D.geom + (size_t)psid * 4, pinside, eps);
+                const double cosi = dot(sf.N, pd);
                 const int br = D.node_branch[k];
                 if (br == 0) {
-                    // transmitted ray (reference raytrace.py:198-212, :104-107); the same
-                    // operations on the same stored values as in the parent's own pass
-                    double ior = D.mat[(size_t)psid * RT_MAT_WIDTH + 12];
-                    double mu = pinside ? ior / air : air / ior;
-                    double kk = 1 - mu * mu * (1 - cosi * cosi);
-                    double sk = sqrt(fmax(kk, 0.0));
-                    d = sk * N + mu * (pd - cosi * N);
-                    o = Pb + (2 * eps) * N;
+                    // transmitted ray (reference raytrace.py:198-212, :104-107): the same
+                    // operations on the same values as in the parent's own pass
+                    const double ior = D.mat[(size_t)psid * RT_MAT_WIDTH + 12];
+                    const double mu = pinside ? ior / air : air / ior;
+                    const double kk = 1 - mu * mu * (1 - cosi * cosi);
+                    const double sk = sqrt(fmax(kk, 0.0));
+                    d = sk * sf.N + mu * (pd - cosi * sf.N);
+                    o = sf.Pb + (2 * eps) * sf.N;
                     live = pinfo & I_LIVE_TI;
                 } else {
                     // mirror direction about the surface (reference raytrace.py:192-195);
                     // total internal reflection and plain reflection share it
-                    d = pd - cosi * (2.0 * N);
-                    o = Pb;
+                    d = pd - cosi * (2.0 * sf.N);
+                    o = sf.Pb;
                     live = (br == 1) ? (pinfo & I_LIVE_TI) : (pinfo & I_LIVE_R);
                 }
             }
@@ -272,7 +307,8 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
             if (a != 0 && b != 0 && !trans) info |= I_CHILD_I;
             if (a != 0) info |= I_CHILD_R;
             if (live) {
-                info |= I_LIVE;
+                // weights of reference raytrace.py:164-166; a zero weight is an exact zero there too
+                if ((1 - m[11]) * (1 - A) != 0) info |= I_SHADE;
                 if (m[11] * (1 - A) != 0) info |= I_LIVE_TI;
                 if (A != 0) info |= I_LIVE_R;
             }
@@ -287,30 +323,18 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
                     if (rho <= edge) info |= 1u << (I_BEAM_SHIFT + l);
                 }
             }
-            D.px[idx] = Pb.x; D.py[idx] = Pb.y; D.pz[idx] = Pb.z;
+            D.px[idx] = P.x; D.py[idx] = P.y; D.pz[idx] = P.z;
             D.dx[idx] = d.x; D.dy[idx] = d.y; D.dz[idx] = d.z;
-            D.nx[idx] = N.x; D.ny[idx] = N.y; D.nz[idx] = N.z;
             D.A[idx] = A;
             D.dist[idx] = through;
         }
         if (valid) D.info[idx] = info;
 
         // ---- per-tile counters --------------------------------------------------------------
-        {
-            unsigned long long m_t = __ballot((info & I_CHILD_T) != 0);
-            unsigned long long m_i = __ballot((info & I_CHILD_I) != 0);
-            unsigned long long m_r = __ballot((info & I_CHILD_R) != 0);
-            unsigned long long m_h = __ballot((info & I_HIT) != 0);
-            if (lane == 0) {
-                s_wcnt[wave][C_T] = __popcll(m_t);
-                s_wcnt[wave][C_I] = __popcll(m_i);
-                s_wcnt[wave][C_R] = __popcll(m_r);
-                s_wcnt[wave][C_HIT] = __popcll(m_h);
-            }
-            for (int l = 0; l < RT_MAX_LIGHTS; ++l) {
-                unsigned long long m_b = __ballot(((info >> (I_BEAM_SHIFT + l)) & 1u) != 0);
-                if (lane == 0) s_wcnt[wave][C_BEAM0 + l] = __popcll(m_b);
-            }
+#pragma unroll
+        for (int c = 0; c < NCNT; ++c) {
+            unsigned long long mk = __ballot(((info >> counter_bit(c)) & 1u) != 0);
+            if (lane == 0) s_wcnt[wave][c] = __popcll(mk);
         }
         __syncthreads();
         if (tid < NCNT) {
@@ -370,10 +394,11 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
             }
         } else if (c == C_HIT) {
             D.node_hits[k] = (int)tot;
-        } else {
+        } else if (c != C_SHADE) {
             D.node_beam[k * RT_MAX_LIGHTS + (c - C_BEAM0)] = (int)tot;
         }
     }
+    if (tid == 0) D.lvl_shade_base[level + 1] = D.lvl_shade_base[level] + (int)s_grand[C_SHADE];
     __syncthreads();
 
     // 3. layout of the next level: every node gets whole tiles
@@ -405,10 +430,11 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ordered compaction: every child slot of the next level learns its parent.
+// Ordered compaction: every child slot of the next level learns its parent, and the
+// hits that need lighting are appended to the dense shading list.
 __global__ __launch_bounds__(TILE) void k_link(Dev D, int level) {
     __shared__ int s_tile_end[MAX_LEVEL_NODES];
-    __shared__ int s_wcnt[4][3];
+    __shared__ int s_wcnt[4][NCNT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (D.flags[0]) return;  // arena overflow: child slots do not exist
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
@@ -418,6 +444,12 @@ __global__ __launch_bounds__(TILE) void k_link(Dev D, int level) {
     const int q = (nt + NB - 1) / NB;
     const int t_begin = blockIdx.x * q;
     const int t_end = min(nt, t_begin + q);
+    const bool has_children = level + 1 < D.n_levels;
+    const int shade_base = D.lvl_shade_base[level];
+    // counters whose ranks are needed: children, shade items, and what sample addressing uses
+    uint32_t want = (has_children ? 7u : 0u) | (1u << C_SHADE);
+    if (D.list_j[0]) want |= 1u << C_HIT;
+    want |= D.spot_mask << C_BEAM0;
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
         const int k = k0 + find_node(s_tile_end, nn, t);
@@ -425,21 +457,39 @@ __global__ __launch_bounds__(TILE) void k_link(Dev D, int level) {
         const int cnt = min(TILE, D.node_n[k] - first);
         const uint32_t idx = (uint32_t)(tbase + t) * TILE + tid;
         const uint32_t info = (tid < cnt) ? D.info[idx] : 0u;
-        unsigned long long m[3];
-        for (int c = 0; c < 3; ++c) {
-            m[c] = __ballot(((info >> (18 + c)) & 1u) != 0);
-            if (lane == 0) s_wcnt[wave][c] = __popcll(m[c]);
+        int rank[NCNT];
+#pragma unroll
+        for (int c = 0; c < NCNT; ++c) {
+            rank[c] = 0;
+            if ((want >> c) & 1u) {
+                unsigned long long mk = __ballot(((info >> counter_bit(c)) & 1u) != 0);
+                if (lane == 0) s_wcnt[wave][c] = __popcll(mk);
+                rank[c] = lanes_below(mk);
+            }
         }
         __syncthreads();
-        for (int c = 0; c < 3; ++c) {
-            if ((info >> (18 + c)) & 1u) {
-                int rank = lanes_below(m[c]);
-                for (int w = 0; w < wave; ++w) rank += s_wcnt[w][c];
-                const int child = D.node_child[k * 3 + c];
-                const uint32_t slot = D.node_start[child] +
-                                      (gscan(D, level, tbase, q, t, c) - D.node_pre[(size_t)k * NCNT + c]) + rank;
-                D.link[slot] = idx;
+#pragma unroll
+        for (int c = 0; c < NCNT; ++c) {
+            if (((want >> c) & 1u) && ((info >> counter_bit(c)) & 1u)) {
+                for (int w = 0; w < wave; ++w) rank[c] += s_wcnt[w][c];
+                rank[c] += (int)gscan(D, level, tbase, q, t, c);
+                if (c != C_SHADE) rank[c] -= (int)D.node_pre[(size_t)k * NCNT + c];
             }
+        }
+        if (has_children) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if ((info >> (18 + c)) & 1u) D.link[D.node_start[D.node_child[k * 3 + c]] + rank[c]] = idx;
+            }
+        }
+        if (info & I_SHADE) {
+            const int e = shade_base + rank[C_SHADE];
+            D.list_ray[e] = idx;
+            D.list_node[e] = (uint16_t)k;
+            if (D.list_j[0]) D.list_j[0][e] = (uint32_t)rank[C_HIT];
+#pragma unroll
+            for (int l = 0; l < RT_MAX_LIGHTS; ++l)
+                if ((D.spot_mask >> l) & 1u) D.list_j[1 + l][e] = (uint32_t)rank[C_BEAM0 + l];
         }
         __syncthreads();
     }
@@ -520,12 +570,164 @@ __device__ __forceinline__ double ease(int mode, double x, double a, double d) {
     }
 }
 
-// Surface colour of one hit under all lights (reference raytrace.py:136-152,
-// :215-234 and objects.py:94-235).  j_hit / j_beam: rank of the hit among the
-// node's hits / in-beam hits; h_hit / h_beam: those counts.
+// One disk-light sample in float64 (reference objects.py:132-138, :99-110 and
+// raytrace.py:219-232): light intensities and BRDF terms of the sample.
+struct SampleTerms {
+    V3 Id, Is, kd, ks;
+};
 template <bool LDS>
-__device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int node, uint32_t info, V3 Pb, V3 d, V3 n,
-                            const double* m, int j_hit, int h_hit, const int* j_beam, unsigned& n_samples) {
+__device__ SampleTerms disk_sample_f64(const Dev& D, const ShadowSphere* s_sh, const RtLight& Lt, double u_theta,
+                                       double u_rad, V3 Pb, V3 d, V3 n, V3 kdiff, V3 kspec, double shin) {
+    const V3 lpos = ld3(Lt.position), xh = ld3(Lt.x_hat), yh = ld3(Lt.y_hat);
+    const double theta = u_theta * 6.283185307179586;
+    const double rad = sqrt(u_rad) * Lt.radius;
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    V3 lp = lpos + rad * (cs * xh + sn * yh);
+    V3 Lv = lp - Pb;
+    const double dist = sqrt(dot(Lv, Lv));
+    V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
+    V3 mult = shadow_multiplier<LDS>(D, s_sh, Pb, Lh);
+    const double fall = (Lt.intensity / Lt.n_points) / (dist * dist);
+    SampleTerms o;
+    o.Id = clip01((fall * ld3(Lt.diffuse_color)) * mult);
+    o.Is = clip01((fall * ld3(Lt.specular_color)) * mult);
+    const double nl = dot(n, Lh);
+    V3 Rv = Lh - (2 * nl) * n;
+    const double rd = fabs(dot(Rv, d));
+    o.kd = clip01(nl * kdiff);
+    o.ks = clip01(pow_shininess(rd, shin) * kspec);
+    return o;
+}
+
+// ---- float32 evaluation of disk-light samples --------------------------------------------
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(V3 v) { return {(float)v.x, (float)v.y, (float)v.z}; }
+__device__ __forceinline__ V3 v3(F3 v) { return {(double)v.x, (double)v.y, (double)v.z}; }
+__device__ __forceinline__ float fdot(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ float fclip01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
+__device__ __forceinline__ F3 fclip01(F3 v) { return {fclip01(v.x), fclip01(v.y), fclip01(v.z)}; }
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+constexpr int SREG = 4;  // spheres whose hit-relative data the float32 path keeps in registers
+
+// What a shadow ray from one hit needs of one sphere, relative to the hit: computed once
+// per hit in float64, then rounded.  With |d| = 1 the ray hits iff b^2 - C >= 0 and one
+// root is positive, b = oc.d, C = |oc|^2 - r^2.
+struct HitSphere {
+    F3 oc;      // Pb - centre
+    float C;    // |oc|^2 - r^2, sign exact (origin inside the sphere iff C < 0)
+    float len;  // |oc|
+    float k0;   // error bound of C (float rounding + float64 cancellation noise)
+};
+
+// All samples of one disk light for one hit in float32, with every shadow decision
+// certified: the discriminant of each (sample, sphere) test carries a rigorous error
+// bound.  A sample with a decision inside its bound is only counted here (n_unsure); the
+// caller then queues the whole hit for re-evaluation in float64 (k_surface_redo), so the
+// set of occluders that reaches the image always equals the float64 path's.  Samples are
+// fetched eight at a time so that their loads are in flight together.
+constexpr int SAMPLE_BATCH = 8;
+template <bool LDS>
+__device__ void disk_light_mixed(const Dev& D, const ShadowSphere* s_sh, const RtLight& Lt, const double* pk,
+                                 int64_t stride, V3 Pb, V3 d, V3 n, V3 kdiff, V3 kspec,
+                                 double shin, V3& sumId, V3& sumIs, V3& sumKd, V3& sumKs, unsigned& n_unsure) {
+    const int S = D.S;
+    HitSphere hs[SREG];
+#pragma unroll
+    for (int i = 0; i < SREG; ++i) {
+        if (i < S) {
+            const ShadowSphere sp = LDS ? s_sh[i] : ShadowSphere{D.geom[i * 4], D.geom[i * 4 + 1], D.geom[i * 4 + 2],
+                                                                   D.geom[i * 4 + 3] * D.geom[i * 4 + 3], 0, 0, 0, 0};
+            const V3 oc = {Pb.x - sp.cx, Pb.y - sp.cy, Pb.z - sp.cz};
+            const double l2 = dot(oc, oc);
+            const double C = l2 - sp.r2;
+            hs[i].oc = f3(oc);
+            hs[i].C = (float)C;
+            hs[i].len = (float)sqrt(l2) * 1.0000002f;
+            hs[i].k0 = (float)(1.5e-7 * fabs(C) + 1e-15 * (l2 + sp.r2));
+        } else {
+            hs[i].oc = {0, 0, 0}; hs[i].C = 1; hs[i].len = 0; hs[i].k0 = 0;
+        }
+    }
+    const F3 q = f3(ld3(Lt.position) - Pb);
+    const F3 xh = f3(ld3(Lt.x_hat)), yh = f3(ld3(Lt.y_hat));
+    const F3 nf = f3(n), df = f3(d), kdf = f3(kdiff), ksf = f3(kspec);
+    const F3 dcol = f3(ld3(Lt.diffuse_color)), scol = f3(ld3(Lt.specular_color));
+    const float Rf = (float)Lt.radius, per_sample = (float)(Lt.intensity / Lt.n_points), shf = (float)shin;
+    const float frame = sqrtf(fmaxf(fdot(xh, xh), fdot(yh, yh)));  // the disk frame is not normalised
+    const int N = Lt.n_points;
+    F3 aId = {0, 0, 0}, aIs = {0, 0, 0}, aKd = {0, 0, 0}, aKs = {0, 0, 0};
+    for (int s0 = 0; s0 < N; s0 += SAMPLE_BATCH) {
+        float ut[SAMPLE_BATCH], ur[SAMPLE_BATCH];
+#pragma unroll
+        for (int k = 0; k < SAMPLE_BATCH; ++k) {
+            const double2 u = *reinterpret_cast<const double2*>(pk + (int64_t)min(s0 + k, N - 1) * stride);
+            ut[k] = (float)u.x;
+            ur[k] = (float)u.y;
+        }
+#pragma unroll
+        for (int k = 0; k < SAMPLE_BATCH; ++k) {
+            if (s0 + k >= N) break;
+            const float sn = __builtin_amdgcn_sinf(ut[k]), cs = __builtin_amdgcn_cosf(ut[k]);  // argument in revolutions
+            const float rad = __builtin_amdgcn_sqrtf(ur[k]) * Rf;
+            F3 Lv = {fmaf(rad, fmaf(cs, xh.x, sn * yh.x), q.x), fmaf(rad, fmaf(cs, xh.y, sn * yh.y), q.y),
+                     fmaf(rad, fmaf(cs, xh.z, sn * yh.z), q.z)};
+            const float d2 = fdot(Lv, Lv);
+            const float inv = __builtin_amdgcn_rsqf(d2);
+            const F3 Lh = {Lv.x * inv, Lv.y * inv, Lv.z * inv};
+            // bound of |Lh - exact unit light vector|: light point (sin/cos 1.3e-7, u -> float
+            // 3.8e-7 rad, sqrt 1e-7, all times the disk radius) over the distance, plus rounding
+            const float eL = fmaf(1.5e-6f * Rf * frame, inv, 6e-7f);
+            F3 mult = {1, 1, 1};
+            bool unsure = false;
+#pragma unroll
+            for (int i = 0; i < SREG; ++i) {
+                if (i < S) {
+                    const float b = fdot(hs[i].oc, Lh);
+                    const float disc = fmaf(b, b, -hs[i].C);
+                    const float db = hs[i].len * eL;
+                    const float m = fmaf(2.0f * fabsf(b), db, fmaf(db, db, hs[i].k0));
+                    if (fabsf(disc) <= m) {
+                        unsure = true;
+                    } else if (disc > 0 && (b < 0 || hs[i].C < 0)) {
+                        const ShadowSphere sp = LDS ? s_sh[i]
+                                                    : ShadowSphere{0, 0, 0, 0, D.mat[i * RT_MAT_WIDTH + 11],
+                                                                   D.mat[i * RT_MAT_WIDTH + 14] * D.mat[i * RT_MAT_WIDTH + 15],
+                                                                   D.mat[i * RT_MAT_WIDTH + 14] * D.mat[i * RT_MAT_WIDTH + 16],
+                                                                   D.mat[i * RT_MAT_WIDTH + 14] * D.mat[i * RT_MAT_WIDTH + 17]};
+                        const float tr = (float)sp.tr;
+                        const float chord = hs[i].C > 0 ? 2.0f * __builtin_amdgcn_sqrtf(disc) : 0.0f;
+                        mult.x *= tr * fexp(-(float)sp.kr * chord);
+                        mult.y *= tr * fexp(-(float)sp.kg * chord);
+                        mult.z *= tr * fexp(-(float)sp.kb * chord);
+                    }
+                }
+            }
+            if (unsure) n_unsure += 1;
+            const float fall = per_sample * inv * inv;
+            aId.x += fclip01(fall * dcol.x * mult.x); aId.y += fclip01(fall * dcol.y * mult.y); aId.z += fclip01(fall * dcol.z * mult.z);
+            aIs.x += fclip01(fall * scol.x * mult.x); aIs.y += fclip01(fall * scol.y * mult.y); aIs.z += fclip01(fall * scol.z * mult.z);
+            const float nl = fdot(nf, Lh);
+            const float two_nl = 2.0f * nl;
+            const F3 Rv = {fmaf(-two_nl, nf.x, Lh.x), fmaf(-two_nl, nf.y, Lh.y), fmaf(-two_nl, nf.z, Lh.z)};
+            const float rd = fabsf(fdot(Rv, df));
+            const float p = shf == 0 ? 1.0f : __builtin_amdgcn_exp2f(shf * __builtin_amdgcn_logf(rd));
+            aKd.x += fclip01(nl * kdf.x); aKd.y += fclip01(nl * kdf.y); aKd.z += fclip01(nl * kdf.z);
+            aKs.x += fclip01(p * ksf.x); aKs.y += fclip01(p * ksf.y); aKs.z += fclip01(p * ksf.z);
+        }
+    }
+    sumId = v3(aId); sumIs = v3(aIs); sumKd = v3(aKd); sumKs = v3(aKs);
+}
+
+// Surface colour of one hit under all lights (reference raytrace.py:136-152,
+// :215-234 and objects.py:94-235).  entry: index of the hit in the shading list,
+// which is also the index of its disk-light samples in the packed sample buffer.
+template <bool LDS, bool MIXED>
+__device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int64_t entry, uint32_t info, V3 Pb, V3 d, V3 n,
+                            const double* m, unsigned& n_samples, unsigned& n_fallback) {
     const SceneConst& sc = *D.sc;
     const V3 kdiff = ld3(m + 3), kspec = ld3(m + 6);
     const double shin = m[9];
@@ -533,8 +735,8 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int node, ui
     for (int l = 0; l < D.n_lights; ++l) {
         const RtLight& Lt = sc.lights[l];
         const V3 lpos = ld3(Lt.position);
-        const V3 dcol = ld3(Lt.diffuse_color), scol = ld3(Lt.specular_color);
         if (Lt.kind == RT_LIGHT_POINT) {
+            const V3 dcol = ld3(Lt.diffuse_color), scol = ld3(Lt.specular_color);
             V3 Lv = lpos - Pb;
             const double d2 = dot(Lv, Lv);
             const double dist = sqrt(d2);
@@ -551,12 +753,9 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int node, ui
             continue;
         }
         // disk light, possibly restricted to a beam
-        int j = j_hit, h = h_hit;
         double factor = 1.0;
         if (Lt.kind == RT_LIGHT_SPOT) {
             if (!((info >> (I_BEAM_SHIFT + l)) & 1u)) continue;  // zero light vectors, zero intensity
-            j = j_beam[l];
-            h = D.node_beam[node * RT_MAX_LIGHTS + l];
             V3 rel = Pb - lpos;
             const double x = dot(ld3(Lt.x_hat), rel), y = dot(ld3(Lt.y_hat), rel), z = dot(ld3(Lt.normal), rel);
             const double rho = sqrt(x * x + y * y);
@@ -566,30 +765,18 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int node, ui
         }
         const int N = Lt.n_points;
         n_samples += N;
-        const int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
-        const double* u_theta = D.samples + off + j;
-        const double* u_rad = D.samples + off + (int64_t)N * h + j;
-        const V3 xh = ld3(Lt.x_hat), yh = ld3(Lt.y_hat);
-        const double per_sample = Lt.intensity / N;
+        const double* pk = D.packed + 2 * (D.pack_base[l] + entry);   // + 2 * pack_E per sample
+        const int64_t stride = 2 * D.pack_E;
         V3 sumId = {0, 0, 0}, sumIs = {0, 0, 0}, sumKd = {0, 0, 0}, sumKs = {0, 0, 0};
-        for (int s = 0; s < N; ++s) {
-            const double theta = u_theta[(int64_t)s * h] * 6.283185307179586;
-            const double rad = sqrt(u_rad[(int64_t)s * h]) * Lt.radius;
-            double sn, cs;
-            sincos(theta, &sn, &cs);
-            V3 lp = lpos + rad * (cs * xh + sn * yh);
-            V3 Lv = lp - Pb;
-            const double dist = sqrt(dot(Lv, Lv));
-            V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
-            V3 mult = shadow_multiplier<LDS>(D, s_sh, Pb, Lh);
-            const double fall = per_sample / (dist * dist);
-            sumId = sumId + clip01((fall * dcol) * mult);
-            sumIs = sumIs + clip01((fall * scol) * mult);
-            const double nl = dot(n, Lh);
-            V3 Rv = Lh - (2 * nl) * n;
-            const double rd = fabs(dot(Rv, d));
-            sumKd = sumKd + clip01(nl * kdiff);
-            sumKs = sumKs + clip01(pow_shininess(rd, shin) * kspec);
+        if constexpr (MIXED) {   // the host launches this variant only when S <= SREG
+            disk_light_mixed<LDS>(D, s_sh, Lt, pk, stride, Pb, d, n, kdiff, kspec, shin, sumId, sumIs, sumKd, sumKs,
+                                  n_fallback);
+        } else {
+            for (int s = 0; s < N; ++s) {
+                const SampleTerms o = disk_sample_f64<LDS>(D, s_sh, Lt, pk[s * stride], pk[s * stride + 1],
+                                                           Pb, d, n, kdiff, kspec, shin);
+                sumId = sumId + o.Id; sumIs = sumIs + o.Is; sumKd = sumKd + o.kd; sumKs = sumKs + o.ks;
+            }
         }
         const double invN = 1.0 / N;
         V3 Id = clip01(invN * sumId), Is = clip01(invN * sumIs);
@@ -604,25 +791,59 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int node, ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// Lighting + bottom-up combination for one level (deepest level first).
-template <bool LDS>
-__global__ __launch_bounds__(TILE) void k_shade(Dev D, int level) {
-    __shared__ int s_tile_end[MAX_LEVEL_NODES];
-    __shared__ int s_wcnt[4][NCNT];
+// Sample packing.  The caller's random stream is laid out as the reference consumes it:
+// the block of (node, light) holds all angle uniforms and then all radius uniforms, each
+// as n_points rows of h values (h = the node's hits, or in-beam hits for a spotlight),
+// and the hit with rank j owns column j (reference objects.py:122, :132-133).  Only the
+// hits on the shading list ever read their columns, so every uploaded piece of the
+// stream, chunk[0..n) = stream[a..a+n), is scattered straight into the packed layout
+// (entry-major within a sample, so k_surface reads it fully coalesced).
+__global__ __launch_bounds__(TILE) void k_pack(Dev D, const double* chunk, int64_t a, int64_t n) {
+    const SceneConst& sc = *D.sc;
+    const int64_t b = a + n;
+    const int64_t E = D.pack_E;
+    for (int64_t e = (int64_t)blockIdx.x * TILE + threadIdx.x; e < E; e += (int64_t)gridDim.x * TILE) {
+        const uint32_t info = D.info[D.list_ray[e]];
+        const int node = D.list_node[e];
+        for (int l = 0; l < D.n_lights; ++l) {
+            const RtLight& Lt = sc.lights[l];
+            if (Lt.kind == RT_LIGHT_POINT) continue;
+            int64_t h, jj;
+            if (Lt.kind == RT_LIGHT_SPOT) {
+                if (!((info >> (I_BEAM_SHIFT + l)) & 1u)) continue;
+                h = D.node_beam[node * RT_MAX_LIGHTS + l];
+                jj = D.list_j[1 + l][e];
+            } else {
+                h = D.node_hits[node];
+                jj = D.list_j[0][e];
+            }
+            const int N = Lt.n_points;
+            const int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
+            if (off < 0 || off + 2 * N * h <= a || off >= b) continue;
+            double* dst = D.packed + 2 * (D.pack_base[l] + e);
+            for (int part = 0; part < 2; ++part) {
+                const int64_t first = off + (int64_t)part * N * h + jj;     // stream position of row 0
+                int64_t s0 = first >= a ? 0 : (a - first + h - 1) / h;
+                for (int64_t s = s0; s < N; ++s) {
+                    const int64_t pos = first + s * h;
+                    if (pos >= b) break;
+                    dst[2 * s * E + part] = chunk[pos - a];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lighting for the dense list of hits whose surface colour matters (all levels).
+template <bool LDS, bool MIXED>
+__global__ __launch_bounds__(TILE, MIXED ? RT_MIXED_WAVES : 2) void k_surface(Dev D) {
     __shared__ ShadowSphere s_sh[LDS ? SHADE_LDS_SPHERES : 1];
-    __shared__ unsigned s_work[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ unsigned s_work[3];
+    const int tid = threadIdx.x;
     if (D.flags[0]) return;  // arena overflow: the frame is invalid, the host reports it
-    if (tid < 2) s_work[tid] = 0;
-    unsigned my_hits = 0, my_samples = 0;
-    const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
-    for (int i = tid; i < nn; i += TILE) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
-    const int nt = D.lvl_ntiles[level];
-    const int tbase = D.lvl_tilebase[level];
-    const int q = (nt + NB - 1) / NB;
-    const int t_begin = blockIdx.x * q;
-    const int t_end = min(nt, t_begin + q);
-    if (LDS && t_begin < t_end) {
+    if (tid < 3) s_work[tid] = 0;
+    if (LDS) {
         for (int i = tid; i < D.S; i += TILE) {
             const double* g = D.geom + (size_t)i * 4;
             const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
@@ -630,8 +851,87 @@ __global__ __launch_bounds__(TILE) void k_shade(Dev D, int level) {
         }
     }
     __syncthreads();
+    const double eps = D.sc->eps;
+    const int total = D.lvl_shade_base[D.n_levels];
+    unsigned my_hits = 0, my_samples = 0, my_fallback = 0;
+    for (int e = blockIdx.x * TILE + tid; e < total; e += gridDim.x * TILE) {
+        const uint32_t ray = D.list_ray[e];
+        const uint32_t info = D.info[ray];
+        const int sid = info & I_SID_MASK;
+        const double* g = D.geom + (size_t)sid * 4;
+        const double* m = D.mat + (size_t)sid * RT_MAT_WIDTH;
+        V3 P = {D.px[ray], D.py[ray], D.pz[ray]};
+        V3 d = {D.dx[ray], D.dy[ray], D.dz[ray]};
+        const Surface sf = surface_at(P, g, info & I_INSIDE, eps);
+        unsigned unsure = 0;
+        V3 surf = surface_color<LDS, MIXED>(D, s_sh, e, info, sf.Pb, d, sf.n, m, my_samples, unsure);
+        my_hits += 1;
+        D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
+        if (MIXED && unsure) {
+            // some shadow decision of this hit could not be certified in float32
+            my_fallback += unsure;
+            D.redo_list[atomicAdd(&D.flags[1], 1)] = (uint32_t)e;
+        }
+    }
+    if (my_hits) {
+        atomicAdd(&s_work[0], my_hits);
+        atomicAdd(&s_work[1], my_samples);
+        if (my_fallback) atomicAdd(&s_work[2], my_fallback);
+    }
+    __syncthreads();
+    if (tid < 3 && s_work[tid]) atomicAdd(&D.work[tid], (unsigned long long)s_work[tid]);
+}
+
+// Float64 re-evaluation of the hits the mixed-precision pass queued.
+template <bool LDS>
+__global__ __launch_bounds__(TILE) void k_surface_redo(Dev D) {
+    __shared__ ShadowSphere s_sh[LDS ? SHADE_LDS_SPHERES : 1];
+    const int tid = threadIdx.x;
+    if (D.flags[0]) return;
+    const int total = D.flags[1];
+    if (total == 0) return;
+    if (LDS) {
+        for (int i = tid; i < D.S; i += TILE) {
+            const double* g = D.geom + (size_t)i * 4;
+            const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
+            s_sh[i] = {g[0], g[1], g[2], g[3] * g[3], m[11], m[14] * m[15], m[14] * m[16], m[14] * m[17]};
+        }
+    }
+    __syncthreads();
+    const double eps = D.sc->eps;
+    for (int i = blockIdx.x * TILE + tid; i < total; i += gridDim.x * TILE) {
+        const int64_t e = D.redo_list[i];
+        const uint32_t ray = D.list_ray[e];
+        const uint32_t info = D.info[ray];
+        const int sid = info & I_SID_MASK;
+        V3 P = {D.px[ray], D.py[ray], D.pz[ray]};
+        V3 d = {D.dx[ray], D.dy[ray], D.dz[ray]};
+        const Surface sf = surface_at(P, D.geom + (size_t)sid * 4, info & I_INSIDE, eps);
+        unsigned a = 0, b = 0;
+        V3 surf = surface_color<LDS, false>(D, s_sh, e, info, sf.Pb, d, sf.n, D.mat + (size_t)sid * RT_MAT_WIDTH, a, b);
+        D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bottom-up colour combination for one level (reference raytrace.py:155-170); the
+// deepest level runs first.  A ray's colour replaces its surface colour in place.
+__global__ __launch_bounds__(TILE) void k_combine(Dev D, int level) {
+    __shared__ int s_tile_end[MAX_LEVEL_NODES];
+    __shared__ int s_wcnt[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (D.flags[0]) return;
+    const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
+    for (int i = tid; i < nn; i += TILE) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
+    const int nt = D.lvl_ntiles[level];
+    const int tbase = D.lvl_tilebase[level];
+    const int q = (nt + NB - 1) / NB;
+    const int t_begin = blockIdx.x * q;
+    const int t_end = min(nt, t_begin + q);
+    __syncthreads();
     const SceneConst& sc = *D.sc;
     const V3 bg = ld3(sc.bg);
+    const bool has_children = level + 1 < D.n_levels;
 
     for (int t = t_begin; t < t_end; ++t) {
         const int k = k0 + find_node(s_tile_end, nn, t);
@@ -641,64 +941,51 @@ __global__ __launch_bounds__(TILE) void k_shade(Dev D, int level) {
         const bool valid = tid < cnt;
         const uint32_t info = valid ? D.info[idx] : 0u;
 
-        // ranks inside the tile for every counter
-        unsigned long long masks[NCNT];
-        for (int c = 0; c < NCNT; ++c) {
-            const int bit = (c < 3) ? 18 + c : (c == C_HIT ? 16 : I_BEAM_SHIFT + (c - C_BEAM0));
-            masks[c] = __ballot(((info >> bit) & 1u) != 0);
-            if (lane == 0) s_wcnt[wave][c] = __popcll(masks[c]);
+        int rank[3] = {0, 0, 0};
+        if (has_children) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                unsigned long long mk = __ballot(((info >> (18 + c)) & 1u) != 0);
+                if (lane == 0) s_wcnt[wave][c] = __popcll(mk);
+                rank[c] = lanes_below(mk);
+            }
+            __syncthreads();
         }
-        __syncthreads();
 
         if (valid) {
             V3 col = bg;
             if (info & I_HIT) {
-                col = {0, 0, 0};
-                if (info & I_LIVE) {
-                    int rank[NCNT];
-                    for (int c = 0; c < NCNT; ++c) {
-                        int r = lanes_below(masks[c]);
-                        for (int w = 0; w < wave; ++w) r += s_wcnt[w][c];
-                        rank[c] = r + (int)(gscan(D, level, tbase, q, t, c) - D.node_pre[(size_t)k * NCNT + c]);
+                const int sid = info & I_SID_MASK;
+                const bool inside = info & I_INSIDE;
+                const double* m = D.mat + (size_t)sid * RT_MAT_WIDTH;
+                const double A = D.A[idx];
+                const double tr = m[11];
+                V3 surf = {0, 0, 0}, refr = {0, 0, 0}, refl = {0, 0, 0};
+                if (info & I_SHADE) surf = {D.cr[idx], D.cg[idx], D.cb[idx]};
+                if ((info & I_LIVE_TI) && (info & (I_CHILD_T | I_CHILD_I))) {
+                    const int c = (info & I_CHILD_T) ? C_T : C_I;
+                    int r = rank[c];
+                    for (int w = 0; w < wave; ++w) r += s_wcnt[w][c];
+                    r += (int)(gscan(D, level, tbase, q, t, c) - D.node_pre[(size_t)k * NCNT + c]);
+                    const uint32_t slot = D.node_start[D.node_child[k * 3 + c]] + r;
+                    refr = {D.cr[slot], D.cg[slot], D.cb[slot]};
+                    if ((info & I_CHILD_T) && !inside) {
+                        // absorption inside the entered sphere (reference raytrace.py:119-120)
+                        const double through = D.dist[idx];
+                        const double att = m[14];
+                        refr.x *= exp(-att * m[15] * through);
+                        refr.y *= exp(-att * m[16] * through);
+                        refr.z *= exp(-att * m[17] * through);
                     }
-                    const int sid = info & I_SID_MASK;
-                    const bool inside = info & I_INSIDE;
-                    const double* g = D.geom + (size_t)sid * 4;
-                    const double* m = D.mat + (size_t)sid * RT_MAT_WIDTH;
-                    V3 Pb = {D.px[idx], D.py[idx], D.pz[idx]};
-                    V3 d = {D.dx[idx], D.dy[idx], D.dz[idx]};
-                    const double A = D.A[idx];
-                    const double tr = m[11];
-                    const double w_surf = (1 - tr) * (1 - A);
-                    V3 surf = {0, 0, 0};
-                    if (w_surf != 0) {
-                        V3 N = {D.nx[idx], D.ny[idx], D.nz[idx]};
-                        V3 n = inside ? N : -N;  // outward normal
-                        surf = surface_color<LDS>(D, s_sh, k, info, Pb, d, n, m, rank[C_HIT], D.node_hits[k],
-                                                  rank + C_BEAM0, my_samples);
-                        my_hits += 1;
-                    }
-                    V3 refr = {0, 0, 0}, refl = {0, 0, 0};
-                    if ((info & I_LIVE_TI) && (info & (I_CHILD_T | I_CHILD_I))) {
-                        const int c = (info & I_CHILD_T) ? C_T : C_I;
-                        const uint32_t slot = D.node_start[D.node_child[k * 3 + c]] + rank[c];
-                        refr = {D.cr[slot], D.cg[slot], D.cb[slot]};
-                        if ((info & I_CHILD_T) && !inside) {
-                            // absorption inside the entered sphere (reference raytrace.py:119-120)
-                            const double through = D.dist[idx];
-                            const double att = m[14];
-                            refr.x *= exp(-att * m[15] * through);
-                            refr.y *= exp(-att * m[16] * through);
-                            refr.z *= exp(-att * m[17] * through);
-                        }
-                    }
-                    if ((info & I_LIVE_R) && (info & I_CHILD_R)) {
-                        const uint32_t slot = D.node_start[D.node_child[k * 3 + C_R]] + rank[C_R];
-                        refl = {D.cr[slot], D.cg[slot], D.cb[slot]};
-                    }
-                    // reference raytrace.py:155-170
-                    col = clip01(w_surf * surf + (tr * (1 - A)) * refr + A * refl);
                 }
+                if ((info & I_LIVE_R) && (info & I_CHILD_R)) {
+                    int r = rank[C_R];
+                    for (int w = 0; w < wave; ++w) r += s_wcnt[w][C_R];
+                    r += (int)(gscan(D, level, tbase, q, t, C_R) - D.node_pre[(size_t)k * NCNT + C_R]);
+                    const uint32_t slot = D.node_start[D.node_child[k * 3 + C_R]] + r;
+                    refl = {D.cr[slot], D.cg[slot], D.cb[slot]};
+                }
+                col = clip01(((1 - tr) * (1 - A)) * surf + (tr * (1 - A)) * refr + A * refl);
             }
             D.cr[idx] = col.x; D.cg[idx] = col.y; D.cb[idx] = col.z;
             if (level == 0) {
@@ -706,17 +993,8 @@ __global__ __launch_bounds__(TILE) void k_shade(Dev D, int level) {
                 out[0] = col.x; out[1] = col.y; out[2] = col.z;
             }
         }
-        __syncthreads();
+        if (has_children) __syncthreads();
     }
-    if (my_hits) {
-        atomicAdd(&s_work[0], my_hits);
-        atomicAdd(&s_work[1], my_samples);
-    }
-    __syncthreads();
-    if (tid < 2 && s_work[tid]) atomicAdd(&D.work[tid], (unsigned long long)s_work[tid]);
 }
-
-template __global__ void k_shade<true>(Dev, int);
-template __global__ void k_shade<false>(Dev, int);
 
 }  // namespace rt

@@ -32,7 +32,7 @@ SAMPLE_CHUNK = 1 << 24  # uniforms drawn and uploaded per step (128 MiB)
 class Renderer:
     """A scene bound to one GPU; renders whole frames, row blocks or pixel lists."""
 
-    def __init__(self, scene, params=None, device=0, stream=None, rng=None):
+    def __init__(self, scene, params=None, device=0, stream=None, rng=None, precision="mixed"):
         self.flat = scene if isinstance(scene, FlatScene) else flatten_scene(scene)
         if params is None:
             params = RenderParams(width=int(self.flat.pixels_x), height=int(self.flat.pixels_y))
@@ -41,6 +41,7 @@ class Renderer:
         self.rng = np.random if rng is None else rng
         self.ctx = _native.Context(device, stream)
         self.ctx.set_scene(self.flat, params, self.tree)
+        self.ctx.set_precision(precision)
         self._begin = None
         self.arena_rays = 0
         self.samples_total = 0
@@ -119,7 +120,7 @@ class Renderer:
         return self.ctx.counters()
 
 
-def raytrace(scene, *, params=None, device=0):
+def raytrace(scene, *, params=None, device=0, precision="mixed"):
     """Render ``scene``; returns a ``(height, width, 3)`` float64 image in [0, 1].
 
     Same meaning as the reference's ``raytrace(scene)`` (reference
@@ -127,14 +128,19 @@ def raytrace(scene, *, params=None, device=0):
     (default: the scene's screen size with the current ``constants`` limits).
     Disk-light samples are taken from NumPy's global stream exactly as the
     reference takes them, so ``numpy.random.seed(k)`` before the call selects
-    the same soft shadows."""
-    with Renderer(scene, params, device) as r:
+    the same soft shadows.
+
+    ``precision``: ``"mixed"`` (default) evaluates disk-light samples in float32
+    with float64 re-evaluation of every shadow decision it cannot certify;
+    ``"f64"`` evaluates them in float64 like the reference.  Everything else is
+    float64 in both modes."""
+    with Renderer(scene, params, device, precision=precision) as r:
         r.begin_rows(0, r.params.height)
         img = r.render_pixels()
         return img.reshape(r.params.height, r.params.width, 3)
 
 
-def get_pixel_color(X, Y, scene, *, params=None, device=0):
+def get_pixel_color(X, Y, scene, *, params=None, device=0, precision="mixed"):
     """Colours of the pixels with (possibly fractional) indices ``X``, ``Y``:
     ``(n, 3)`` float64, like the reference's ``get_pixel_color`` (reference
     raytrace.py:6-16).  As in the reference, the small-batch rule applies to the
@@ -143,6 +149,6 @@ def get_pixel_color(X, Y, scene, *, params=None, device=0):
     n = X.size
     if n == 0:
         return np.zeros((0, 3))
-    with Renderer(scene, params, device) as r:
+    with Renderer(scene, params, device, precision=precision) as r:
         r.begin_pixels(X, Y)
         return r.render_pixels()

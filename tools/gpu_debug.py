@@ -7,9 +7,10 @@ from raytracing_amd.Scenes.scenes import build_scene
 
 G = np.load("tests/golden/images_160x90.npz")
 sym = "tir"
+PREC = os.environ.get("RT_PRECISION", "mixed")
 for name in sys.argv[1:] or ["example_1", "example_2", "example_3", "example_4"]:
     np.random.seed(0)
-    with Renderer(build_scene(name, 160, 90)) as r:
+    with Renderer(build_scene(name, 160, 90), precision=PREC) as r:
         r.begin_rows(0, 90)
         img = r.render_pixels().reshape(90, 160, 3)
         tree = r.tree
