@@ -126,7 +126,7 @@ class CpuContext:
         # the next level's queues are complete: check the arena like the device does
         if level + 1 < self.n_levels:
             nxt = range(t.level_start[level + 1], t.level_start[level + 2])
-            need = sum(-(-self.n_local[k] // 256) * 256 for k in nxt)
+            need = sum(-(-self.n_local[k] // 64) * 64 for k in nxt)
             if self.used + need > self.arena_rays:
                 self.overflow = 1
                 for k in nxt:

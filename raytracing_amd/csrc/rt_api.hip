@@ -201,13 +201,14 @@ int use_device(RtContext* ctx) {
 int launch_level(RtContext* ctx, int level) {
     const Dev D = ctx->dev();
     ctx->begin(RT_K_TRACE);
-    hipLaunchKernelGGL(k_trace, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
+    if (ctx->S <= SPH_CHUNK_SMALL) hipLaunchKernelGGL((k_trace<SPH_CHUNK_SMALL>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
+    else hipLaunchKernelGGL((k_trace<SPH_CHUNK_LARGE>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
     ctx->end();
     ctx->begin(RT_K_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, D, level);
     ctx->end();
     ctx->begin(RT_K_LINK);
-    hipLaunchKernelGGL(k_link, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
+    hipLaunchKernelGGL(k_link, dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
     ctx->end();
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -353,7 +354,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     HIP_TRY(ctx->node_start.ensure(K)); HIP_TRY(ctx->node_pre.ensure(K * NCNT));
     HIP_TRY(ctx->lvl_ntiles.ensure(tree.n_levels())); HIP_TRY(ctx->lvl_tilebase.ensure(tree.n_levels()));
     HIP_TRY(ctx->lvl_shade_base.ensure(tree.n_levels() + 1));
-    HIP_TRY(ctx->blk_tot.ensure((size_t)tree.n_levels() * NB * NCNT));
+    HIP_TRY(ctx->blk_tot.ensure((size_t)tree.n_levels() * NW * NCNT));
     HIP_TRY(ctx->flags.ensure(4));
     HIP_TRY(ctx->work.ensure(4));
     HIP_TRY(ctx->sample_off.ensure(K * RT_MAX_LIGHTS));
@@ -535,8 +536,8 @@ int rt_upload_samples(RtContext* ctx, int64_t dst_offset, const double* u, int64
     HIP_TRY(ctx->staging.ensure((size_t)n));
     HIP_TRY(hipMemcpyAsync(ctx->staging.p, u, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (ctx->pack_E > 0) {
-        const int64_t blocks = std::min<int64_t>((ctx->pack_E + TILE - 1) / TILE, 4 * NB);
-        hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(TILE), 0, ctx->stream, ctx->dev(), ctx->staging.p, dst_offset, n);
+        const int64_t blocks = std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB);
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(), ctx->staging.p, dst_offset, n);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller
@@ -552,14 +553,14 @@ int rt_shade(RtContext* ctx) {
     const bool lds = ctx->S <= SHADE_LDS_SPHERES;
     const bool mixed = ctx->precision == RT_PRECISION_MIXED && ctx->sampled_lights && ctx->S <= SREG;
     ctx->begin(RT_K_SURFACE);
-    if (lds && mixed) hipLaunchKernelGGL((k_surface<true, true>), dim3(NB), dim3(TILE), 0, ctx->stream, D);
-    else if (lds) hipLaunchKernelGGL((k_surface<true, false>), dim3(NB), dim3(TILE), 0, ctx->stream, D);
-    else hipLaunchKernelGGL((k_surface<false, false>), dim3(NB), dim3(TILE), 0, ctx->stream, D);
-    if (mixed) hipLaunchKernelGGL((k_surface_redo<true>), dim3(64), dim3(TILE), 0, ctx->stream, D);
+    if (lds && mixed) hipLaunchKernelGGL((k_surface<true, true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    else if (lds) hipLaunchKernelGGL((k_surface<true, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    else hipLaunchKernelGGL((k_surface<false, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    if (mixed) hipLaunchKernelGGL((k_surface_redo<true>), dim3(64), dim3(BLOCK), 0, ctx->stream, D);
     ctx->end();
     for (int level = D.n_levels - 1; level >= 0; --level) {
         ctx->begin(RT_K_COMBINE);
-        hipLaunchKernelGGL(k_combine, dim3(NB), dim3(TILE), 0, ctx->stream, D, level);
+        hipLaunchKernelGGL(k_combine, dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
         ctx->end();
     }
     HIP_TRY(hipGetLastError());

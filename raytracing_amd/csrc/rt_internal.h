@@ -7,21 +7,26 @@
 
 namespace rt {
 
-constexpr int TILE = 256;             // rays per tile = threads per workgroup
+constexpr int TILE = 64;              // rays per tile = one wavefront
+constexpr int BLOCK = 256;            // threads per workgroup
+constexpr int WPB = BLOCK / TILE;     // waves per workgroup
 constexpr int NB = 2048;              // workgroups per level launch (256 CUs x 8)
+constexpr int NW = NB * WPB;          // waves per level launch; each owns a contiguous run of tiles
 constexpr int NCNT = RT_NUM_COUNTERS; // per-tile counters: 3 child kinds, hits, in-beam per light, shade items
 constexpr int MAX_LEVELS = 32;
 constexpr int MAX_LEVEL_NODES = 1024; // widest level of the static ray tree we accept
 constexpr int MAX_NODES = 65536;
-constexpr int SPH_CHUNK = 1024;       // spheres staged in LDS per pass of the nearest-hit loop
+constexpr int SPH_CHUNK_LARGE = 1024; // spheres staged in LDS per pass of the nearest-hit loop
+constexpr int SPH_CHUNK_SMALL = 64;   // ... for scenes with few spheres (less LDS, more resident workgroups)
 constexpr int SHADE_LDS_SPHERES = 512;
 
 // counters
 enum { C_T = 0, C_I = 1, C_R = 2, C_HIT = 3, C_BEAM0 = 4, C_SHADE = 4 + RT_MAX_LIGHTS };
 
 // bits of the per-ray info word
-constexpr uint32_t I_SID_MASK = 0xFFFFu;
-constexpr uint32_t I_HIT = 1u << 16;
+constexpr uint32_t I_SID_MASK = 0xFFFFu;   // sphere hit, I_NO_HIT for a miss
+constexpr uint32_t I_NO_HIT = 0xFFFFu;
+constexpr uint32_t I_LIVE = 1u << 16;      // the ray's colour reaches the pixel with non-zero weight
 constexpr uint32_t I_INSIDE = 1u << 17;
 constexpr uint32_t I_CHILD_T = 1u << 18;  // spawned a transmitted ray
 constexpr uint32_t I_CHILD_I = 1u << 19;  // spawned a total-internal-reflection ray
@@ -70,8 +75,8 @@ struct Dev {
     uint32_t* node_pre;     // [K][NCNT] level-wide running counter value at the node's first tile
     int32_t* lvl_ntiles;    // [n_levels]
     int32_t* lvl_tilebase;  // [n_levels] first tile of the level in the arena
-    uint32_t* tile_run;     // [tiles][NCNT] running counter value inside the producing workgroup
-    uint32_t* blk_tot;      // [n_levels][NB][NCNT] per-workgroup totals, turned into prefixes by k_scan
+    uint32_t* tile_run;     // [tiles][NCNT] running counter value inside the producing wave
+    uint32_t* blk_tot;      // [n_levels][NW][NCNT] per-wave totals, turned into prefixes by k_scan
     int32_t* flags;         // [0] overflow, [1] entries queued for float64 re-evaluation
     unsigned long long* work;  // [0] hits shaded, [1] light samples evaluated (cleared by k_init)
     // ray arena (structure of arrays, one slot per ray)

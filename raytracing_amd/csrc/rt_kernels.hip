@@ -3,7 +3,7 @@
 // One frame is:  k_init, then for every bounce level  k_trace -> k_scan -> k_link,
 // then  k_surface  once, then from the deepest level upwards  k_combine.
 //
-//  * A level's rays live in the arena in tiles of 256, grouped by tree node
+//  * A level's rays live in the arena in tiles of 64 (one wavefront), grouped by tree node
 //    (a node = all rays that followed the same branch sequence, the batch of one
 //    recursive call in reference raytrace.py:19).  Inside a node rays stay in
 //    ascending pixel order, as boolean-mask selection keeps them in the reference.
@@ -66,12 +66,53 @@ __device__ __forceinline__ int find_node(const int* tile_end, int nn, int t) {
 
 // Level-wide running value of counter c at the start of tile t (relative tile index).
 __device__ __forceinline__ unsigned gscan(const Dev& D, int level, int tbase, int q, int t, int c) {
-    return D.blk_tot[((size_t)level * NB + t / q) * NCNT + c] + D.tile_run[(size_t)(tbase + t) * NCNT + c];
+    return D.blk_tot[((size_t)level * NCNT + c) * NW + t / q] + D.tile_run[(size_t)(tbase + t) * NCNT + c];
 }
 
-// Bit of the info word that counter c counts.
-__device__ __forceinline__ int counter_bit(int c) {
-    return c < 3 ? 18 + c : (c == C_HIT ? 16 : (c == C_SHADE ? 21 : I_BEAM_SHIFT + (c - C_BEAM0)));
+// The facts about a node that the tile loops need are fetched with ONE vector load per tile:
+// lane i of the wave reads table i below for node k, and wave-uniform values are then taken
+// with readlane.  (Many small scalar loads per tile are much slower: the scalar unit can only
+// wait for all of its outstanding loads at once.)
+enum { NL_TILE0 = 0, NL_N = 1, NL_NGLOBAL = 2, NL_A = 3, NL_B = 4, NL_BRANCH = 5, NL_CHILD0 = 6, NL_COUNT = 9 };
+struct NodeLane {
+    const int32_t* ptr;
+    int mul, add;
+};
+__device__ __forceinline__ NodeLane node_lane(const Dev& D, int lane) {
+    switch (lane) {
+        case NL_TILE0: return {D.node_tile0, 1, 0};
+        case NL_N: return {D.node_n, 1, 0};
+        case NL_NGLOBAL: return {D.node_nglobal, 1, 0};
+        case NL_A: return {D.node_a, 1, 0};
+        case NL_B: return {D.node_b, 1, 0};
+        case NL_BRANCH: return {D.node_branch, 1, 0};
+        case NL_CHILD0: return {D.node_child, 3, 0};
+        case NL_CHILD0 + 1: return {D.node_child, 3, 1};
+        case NL_CHILD0 + 2: return {D.node_child, 3, 2};
+        default: return {D.node_tile0, 0, 0};
+    }
+}
+__device__ __forceinline__ int node_fetch(const NodeLane& nl, int k, int lane) {
+    return lane < NL_COUNT ? nl.ptr[k * nl.mul + nl.add] : 0;
+}
+#define LANE(v, i) __builtin_amdgcn_readlane((v), (i))
+
+// Lane c: level-wide running value of counter c at the start of tile t, relative to the
+// first tile of node k (not for the shade counter, whose list is level-wide).
+__device__ __forceinline__ int counter_base(const Dev& D, int level, int tbase, int q, int t, int k, int lane) {
+    if (lane >= NCNT) return 0;
+    int v = (int)(D.blk_tot[((size_t)level * NCNT + lane) * NW + t / q] + D.tile_run[(size_t)(tbase + t) * NCNT + lane]);
+    if (lane != C_SHADE) v -= (int)D.node_pre[(size_t)k * NCNT + lane];
+    return v;
+}
+
+__device__ __forceinline__ bool is_hit(uint32_t info) { return (info & I_SID_MASK) != I_NO_HIT; }
+
+// Whether a ray with this info word is counted by counter c.
+__device__ __forceinline__ bool counted(uint32_t info, int c) {
+    if (c == C_HIT) return is_hit(info);
+    const int bit = c < 3 ? 18 + c : (c == C_SHADE ? 21 : I_BEAM_SHIFT + (c - C_BEAM0));
+    return (info >> bit) & 1u;
 }
 
 // Roots of |o + t d - c|^2 = r^2 for unit d; returns false if there is none; lo <= hi.
@@ -154,28 +195,29 @@ __global__ void k_init(Dev D) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Nearest hit + hit record for one level.
-__global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
+// Nearest hit + hit record for one level.  Every wave walks its own run of tiles; the
+// only workgroup-wide steps are staging the spheres in LDS.
+template <int SPH_CHUNK>   // spheres staged in LDS per pass (a small value leaves room for more workgroups)
+__global__ __launch_bounds__(BLOCK) void k_trace(Dev D, int level) {
     __shared__ int s_tile_end[MAX_LEVEL_NODES];
-    __shared__ int s_wcnt[4][NCNT];
     __shared__ double s_sph[SPH_CHUNK][4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
-    for (int i = tid; i < nn; i += TILE) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
+    for (int i = tid; i < nn; i += BLOCK) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
 
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = (nt + NB - 1) / NB;
-    const int t_begin = blockIdx.x * q;
-    const int t_end = min(nt, t_begin + q);
-    unsigned run = 0;  // used by threads 0..NCNT-1
+    const int q = (nt + NW - 1) / NW;                  // tiles per wave (same for every wave)
+    const int wid = blockIdx.x * WPB + wave;
+    const int t_first = wid * q;
+    unsigned run = 0;  // lanes 0..NCNT-1: running counters of this wave
 
     const SceneConst& sc = *D.sc;
     const int S = D.S;
     const bool single_chunk = S <= SPH_CHUNK;
-    if (single_chunk && t_begin < t_end) {
-        for (int i = tid; i < S; i += TILE) {
+    if (single_chunk && blockIdx.x * WPB * q < nt) {
+        for (int i = tid; i < S; i += BLOCK) {
             const double* g = D.geom + (size_t)i * 4;
             s_sph[i][0] = g[0]; s_sph[i][1] = g[1]; s_sph[i][2] = g[2]; s_sph[i][3] = g[3] * g[3];
         }
@@ -184,15 +226,72 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
 
     const double eps = sc.eps, air = sc.air;
 
-    for (int t = t_begin; t < t_end; ++t) {
-        const int k = k0 + find_node(s_tile_end, nn, t);
-        const int first = (t - D.node_tile0[k]) * TILE;
-        const int cnt = min(TILE, D.node_n[k] - first);
-        const bool dead = D.node_nglobal[k] < sc.small_num;   // reference raytrace.py:26-27
-        const int a = D.node_a[k], b = D.node_b[k];
-        const uint32_t idx = (uint32_t)(tbase + t) * TILE + tid;
-        const bool valid = tid < cnt;
-        const bool active = valid && !dead;
+    // Per-tile facts (node, batch, depths): all wave-uniform.
+    struct Meta {
+        bool ok, dead;
+        int t, k, first, cnt, a, b, br;
+    };
+    int kk = (t_first < nt) ? find_node(s_tile_end, nn, t_first) : 0;   // node cursor of the look-ahead
+    auto meta_of = [&](int step) {
+        Meta m;
+        m.t = t_first + step;
+        m.ok = step < q && m.t < nt;
+        m.dead = true;
+        m.k = k0; m.first = 0; m.cnt = 0; m.a = 0; m.b = 0; m.br = 0;
+        if (m.ok) {
+            while (s_tile_end[kk] <= m.t) ++kk;
+            m.k = __builtin_amdgcn_readfirstlane(k0 + kk);
+            // scalar loads: they do not queue behind the vector loads of the prefetch pipeline
+            m.first = (m.t - D.node_tile0[m.k]) * TILE;
+            m.cnt = min(TILE, D.node_n[m.k] - m.first);
+            m.dead = D.node_nglobal[m.k] < sc.small_num;   // reference raytrace.py:26-27
+            m.a = D.node_a[m.k]; m.b = D.node_b[m.k]; m.br = D.node_branch[m.k];
+        }
+        return m;
+    };
+    // What a ray reads of its parent's hit record.
+    struct Parent {
+        uint32_t info;
+        V3 P, d;
+    };
+    auto load_link = [&](const Meta& m) -> uint32_t {
+        return (level > 0 && lane < m.cnt) ? D.link[(uint32_t)(tbase + m.t) * TILE + lane] : 0u;
+    };
+    auto load_parent = [&](const Meta& m, uint32_t p) {
+        Parent r;
+        r.info = 0; r.P = {0, 0, 0}; r.d = {1, 0, 0};
+        if (level > 0 && lane < m.cnt) {
+            r.info = D.info[p];
+            r.P = {D.px[p], D.py[p], D.pz[p]};
+            r.d = {D.dx[p], D.dy[p], D.dz[p]};
+        }
+        return r;
+    };
+
+    // Software pipeline over this wave's tiles: while tile i is computed, the parent records
+    // of tile i+1 and the parent indices of tile i+2 are already in flight.
+    // With more spheres than one LDS chunk the waves of a workgroup must step together.
+    const int steps = single_chunk ? max(0, min(nt, t_first + q) - t_first) : q;
+    Meta m_cur = meta_of(0);
+    uint32_t p_cur = load_link(m_cur);
+    Meta m_nxt = meta_of(1);
+    uint32_t p_nxt = load_link(m_nxt);
+    Parent par_cur = load_parent(m_cur, p_cur);
+    for (int step = 0; step < steps; ++step) {
+        const Parent par_nxt = load_parent(m_nxt, p_nxt);
+        const Meta m_nx2 = meta_of(step + 2);
+        const uint32_t p_nx2 = load_link(m_nx2);
+
+        const Meta m = m_cur;
+        const Parent par = par_cur;
+        m_cur = m_nxt; par_cur = par_nxt; m_nxt = m_nx2; p_nxt = p_nx2;
+
+        const int t = m.t, k = m.k, first = m.first, a = m.a, b = m.b, br = m.br;
+        const bool tile_ok = m.ok;
+        const uint32_t idx = (uint32_t)(tbase + t) * TILE + lane;
+        const bool valid = lane < m.cnt;
+        const bool active = valid && !m.dead;
+        (void)k;
 
         // ---- derive the ray ------------------------------------------------------------------
         V3 o = {0, 0, 0}, d = {1, 0, 0};
@@ -201,7 +300,7 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
             if (level == 0) {
                 // reference objects.py:45-51 and raytrace.py:7-12
                 double X, Y;
-                const int i = first + tid;
+                const int i = first + lane;
                 if (D.X) { X = D.X[i]; Y = D.Y[i]; }
                 else { X = (double)(i % sc.width); Y = (double)(D.row0 + i / sc.width); }
                 double sx = X * sc.scr_w / sc.pix_x - sc.scr_w / 2;
@@ -210,22 +309,19 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
                 o = ld3(sc.cam);
                 d = normalize(pix - o);
             } else {
-                const uint32_t p = D.link[idx];
-                const uint32_t pinfo = D.info[p];
+                const uint32_t pinfo = par.info;
                 const int psid = pinfo & I_SID_MASK;
                 const bool pinside = pinfo & I_INSIDE;
-                V3 P = {D.px[p], D.py[p], D.pz[p]};
-                V3 pd = {D.dx[p], D.dy[p], D.dz[p]};
-                const Surface sf = surface_at(P, D.geom + (size_t)psid * 4, pinside, eps);
+                const V3 pd = par.d;
+                const Surface sf = surface_at(par.P, D.geom + (size_t)psid * 4, pinside, eps);
                 const double cosi = dot(sf.N, pd);
-                const int br = D.node_branch[k];
                 if (br == 0) {
                     // transmitted ray (reference raytrace.py:198-212, :104-107): the same
                     // operations on the same values as in the parent's own pass
                     const double ior = D.mat[(size_t)psid * RT_MAT_WIDTH + 12];
                     const double mu = pinside ? ior / air : air / ior;
-                    const double kk = 1 - mu * mu * (1 - cosi * cosi);
-                    const double sk = sqrt(fmax(kk, 0.0));
+                    const double kk_ = 1 - mu * mu * (1 - cosi * cosi);
+                    const double sk = sqrt(fmax(kk_, 0.0));
                     d = sk * sf.N + mu * (pd - cosi * sf.N);
                     o = sf.Pb + (2 * eps) * sf.N;
                     live = pinfo & I_LIVE_TI;
@@ -247,7 +343,7 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
             const int cn = min(SPH_CHUNK, S - c0);
             if (!single_chunk) {
                 __syncthreads();
-                for (int i = tid; i < cn; i += TILE) {
+                for (int i = tid; i < cn; i += BLOCK) {
                     const double* g = D.geom + (size_t)(c0 + i) * 4;
                     s_sph[i][0] = g[0]; s_sph[i][1] = g[1]; s_sph[i][2] = g[2]; s_sph[i][3] = g[3] * g[3];
                 }
@@ -264,9 +360,10 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
                 }
             }
         }
+        if (!tile_ok) continue;
 
         // ---- hit record (reference raytrace.py:53-101) -------------------------------------
-        uint32_t info = 0;
+        uint32_t info = I_NO_HIT | (live && valid ? I_LIVE : 0u);
         if (active && sid >= 0) {
             const double* g = D.geom + (size_t)sid * 4;
             const double* m = D.mat + (size_t)sid * RT_MAT_WIDTH;
@@ -279,10 +376,10 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
             V3 Pb = P - eps * N;
             const double mu = n1 / n2;
             const double cosi = dot(N, d);
-            const double kk = 1 - mu * mu * (1 - cosi * cosi);
-            const bool trans = kk >= 0;
+            const double kq = 1 - mu * mu * (1 - cosi * cosi);
+            const bool trans = kq >= 0;
             V3 T = {0, 0, 0};
-            if (trans) T = sqrt(kk) * N + mu * (d - cosi * N);  // reference raytrace.py:207-211
+            if (trans) T = sqrt(kq) * N + mu * (d - cosi * N);  // reference raytrace.py:207-211
             double r0 = (n1 - n2) / (n1 + n2);
             r0 *= r0;
             const double cosf = (n2 >= n1) ? cosi : dot(T, N);
@@ -301,7 +398,7 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
                 if (sphere_roots(Pb, T, dot(T, Pb), g[0], g[1], g[2], g[3] * g[3], lo, hi))
                     through = hi > 0 ? hi : (lo > 0 ? lo : -1.0);
             }
-            info = (uint32_t)sid | I_HIT;
+            info = (uint32_t)sid | (live ? I_LIVE : 0u);
             if (inside) info |= I_INSIDE;
             if (b != 0 && trans) info |= I_CHILD_T;
             if (a != 0 && b != 0 && !trans) info |= I_CHILD_I;
@@ -323,27 +420,32 @@ __global__ __launch_bounds__(TILE) void k_trace(Dev D, int level) {
                     if (rho <= edge) info |= 1u << (I_BEAM_SHIFT + l);
                 }
             }
-            D.px[idx] = P.x; D.py[idx] = P.y; D.pz[idx] = P.z;
-            D.dx[idx] = d.x; D.dy[idx] = d.y; D.dz[idx] = d.z;
-            D.A[idx] = A;
-            D.dist[idx] = through;
+            // the record is read by the children (hit point, direction), by k_surface (the
+            // same) and by k_combine (A, path length): store only what somebody will read
+            if ((info & (I_CHILD_T | I_CHILD_I | I_CHILD_R | I_SHADE)) != 0) {
+                D.px[idx] = P.x; D.py[idx] = P.y; D.pz[idx] = P.z;
+                D.dx[idx] = d.x; D.dy[idx] = d.y; D.dz[idx] = d.z;
+            }
+            if (live) {
+                D.A[idx] = A;
+                D.dist[idx] = through;
+            }
         }
         if (valid) D.info[idx] = info;
 
-        // ---- per-tile counters --------------------------------------------------------------
+        // ---- per-tile counters: lane c keeps counter c ---------------------------------------
+        unsigned mine = 0;
 #pragma unroll
         for (int c = 0; c < NCNT; ++c) {
-            unsigned long long mk = __ballot(((info >> counter_bit(c)) & 1u) != 0);
-            if (lane == 0) s_wcnt[wave][c] = __popcll(mk);
+            const unsigned n_c = __popcll(__ballot(counted(info, c)));
+            if (lane == c) mine = n_c;
         }
-        __syncthreads();
-        if (tid < NCNT) {
-            D.tile_run[(size_t)(tbase + t) * NCNT + tid] = run;
-            run += s_wcnt[0][tid] + s_wcnt[1][tid] + s_wcnt[2][tid] + s_wcnt[3][tid];
+        if (lane < NCNT) {
+            D.tile_run[(size_t)(tbase + t) * NCNT + lane] = run;
+            run += mine;
         }
-        __syncthreads();
     }
-    if (tid < NCNT) D.blk_tot[((size_t)level * NB + blockIdx.x) * NCNT + tid] = run;
+    if (lane < NCNT) D.blk_tot[((size_t)level * NCNT + lane) * NW + wid] = run;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -353,23 +455,38 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = max(1, (nt + NB - 1) / NB);
+    const int q = max(1, (nt + NW - 1) / NW);
 
-    // 1. exclusive scan of the workgroup totals, one wave per counter
+    // 1. exclusive scan of the per-wave totals (stored counter-major), one wave per counter;
+    //    every lane owns a run of consecutive entries
     if (wave < NCNT) {
-        unsigned carry = 0;
-        for (int b0 = 0; b0 < NB; b0 += 64) {
-            uint32_t* p = D.blk_tot + ((size_t)level * NB + b0 + lane) * NCNT + wave;
-            unsigned v = *p;
-            unsigned incl = v;
-            for (int off = 1; off < 64; off <<= 1) {
-                unsigned up = __shfl_up(incl, off);
-                if (lane >= off) incl += up;
-            }
-            *p = carry + incl - v;
-            carry += __shfl(incl, 63);
+        constexpr int PER = NW / 64;
+        uint32_t* base = D.blk_tot + ((size_t)level * NCNT + wave) * NW + lane * PER;
+        const uint4* src = reinterpret_cast<const uint4*>(base);
+        unsigned sum = 0;
+#pragma unroll 8
+        for (int i = 0; i < PER / 4; ++i) {
+            const uint4 v = src[i];
+            sum += v.x + v.y + v.z + v.w;
         }
-        if (lane == 0) s_grand[wave] = carry;
+        unsigned incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        unsigned running = incl - sum;
+        uint4* dst = reinterpret_cast<uint4*>(base);
+#pragma unroll 8
+        for (int i = 0; i < PER / 4; ++i) {
+            const uint4 v = src[i];
+            uint4 o;
+            o.x = running; running += v.x;
+            o.y = running; running += v.y;
+            o.z = running; running += v.z;
+            o.w = running; running += v.w;
+            dst[i] = o;
+        }
+        if (lane == 63) s_grand[wave] = incl;
     }
     __syncthreads();
 
@@ -401,48 +518,66 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
     if (tid == 0) D.lvl_shade_base[level + 1] = D.lvl_shade_base[level] + (int)s_grand[C_SHADE];
     __syncthreads();
 
-    // 3. layout of the next level: every node gets whole tiles
-    if (level + 1 < D.n_levels && tid == 0) {
+    // 3. layout of the next level: every node gets whole tiles (block-wide prefix over nodes)
+    if (level + 1 < D.n_levels) {
+        __shared__ int s_wave_tot[16];
         const int c0 = D.level_start[level + 1], c1 = D.level_start[level + 2];
         const int next_base = tbase + nt;
-        int running = 0;
-        for (int k = c0; k < c1; ++k) {
-            const int ntile = (D.node_n[k] + TILE - 1) / TILE;
-            D.node_tile0[k] = running;
-            D.node_ntiles[k] = ntile;
-            D.node_start[k] = (uint32_t)(next_base + running) * TILE;
-            running += ntile;
+        const int k = c0 + tid;
+        const int ntile = (k < c1) ? (D.node_n[k] + TILE - 1) / TILE : 0;
+        int incl = ntile;
+        for (int off = 1; off < 64; off <<= 1) {
+            int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
         }
-        if ((uint32_t)(next_base + running) > D.cap_tiles) {
-            // arena too small: drop the deeper levels and tell the host
-            D.flags[0] = 1;
-            for (int k = c0; k < c1; ++k) {
+        if (lane == 63) s_wave_tot[wave] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) before += s_wave_tot[w];
+            total += s_wave_tot[w];
+        }
+        const int running = before + incl - ntile;
+        const bool overflow = (uint32_t)(next_base + total) > D.cap_tiles;
+        if (k < c1) {
+            if (overflow) {
+                // arena too small: drop the deeper levels and tell the host
                 D.node_n[k] = 0;
                 D.node_nglobal[k] = 0;
                 D.node_tile0[k] = 0;
                 D.node_ntiles[k] = 0;
+            } else {
+                D.node_tile0[k] = running;
+                D.node_ntiles[k] = ntile;
+                D.node_start[k] = (uint32_t)(next_base + running) * TILE;
             }
-            running = 0;
         }
-        D.lvl_ntiles[level + 1] = running;
-        D.lvl_tilebase[level + 1] = next_base;
+        if (tid == 0) {
+            if (overflow) D.flags[0] = 1;
+            D.lvl_ntiles[level + 1] = overflow ? 0 : total;
+            D.lvl_tilebase[level + 1] = next_base;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tiles a wave handles per loop iteration in the bookkeeping kernels: their loads are
+// issued together so that their latencies overlap.
+constexpr int UNROLL_TILES = 4;
+
 // Ordered compaction: every child slot of the next level learns its parent, and the
 // hits that need lighting are appended to the dense shading list.
-__global__ __launch_bounds__(TILE) void k_link(Dev D, int level) {
+__global__ __launch_bounds__(BLOCK) void k_link(Dev D, int level) {
     __shared__ int s_tile_end[MAX_LEVEL_NODES];
-    __shared__ int s_wcnt[4][NCNT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (D.flags[0]) return;  // arena overflow: child slots do not exist
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
-    for (int i = tid; i < nn; i += TILE) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
+    for (int i = tid; i < nn; i += BLOCK) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = (nt + NB - 1) / NB;
-    const int t_begin = blockIdx.x * q;
+    const int q = (nt + NW - 1) / NW;
+    const int wid = blockIdx.x * WPB + wave;
+    const int t_begin = wid * q;
     const int t_end = min(nt, t_begin + q);
     const bool has_children = level + 1 < D.n_levels;
     const int shade_base = D.lvl_shade_base[level];
@@ -451,47 +586,60 @@ __global__ __launch_bounds__(TILE) void k_link(Dev D, int level) {
     if (D.list_j[0]) want |= 1u << C_HIT;
     want |= D.spot_mask << C_BEAM0;
     __syncthreads();
-    for (int t = t_begin; t < t_end; ++t) {
-        const int k = k0 + find_node(s_tile_end, nn, t);
-        const int first = (t - D.node_tile0[k]) * TILE;
-        const int cnt = min(TILE, D.node_n[k] - first);
-        const uint32_t idx = (uint32_t)(tbase + t) * TILE + tid;
-        const uint32_t info = (tid < cnt) ? D.info[idx] : 0u;
-        int rank[NCNT];
+    int kk = (t_begin < t_end) ? find_node(s_tile_end, nn, t_begin) : 0;
+    const NodeLane nl = node_lane(D, lane);
+    for (int t0 = t_begin; t0 < t_end; t0 += UNROLL_TILES) {
+        int k[UNROLL_TILES];
+        uint32_t info[UNROLL_TILES];
+        int base[UNROLL_TILES];         // lane c: rank offset of counter c
+        uint32_t child_at[UNROLL_TILES]; // lane NL_CHILD0 + c: first slot of child node c
+        // phase A: addresses and loads of all tiles of this iteration
 #pragma unroll
-        for (int c = 0; c < NCNT; ++c) {
-            rank[c] = 0;
-            if ((want >> c) & 1u) {
-                unsigned long long mk = __ballot(((info >> counter_bit(c)) & 1u) != 0);
-                if (lane == 0) s_wcnt[wave][c] = __popcll(mk);
-                rank[c] = lanes_below(mk);
+        for (int u = 0; u < UNROLL_TILES; ++u) {
+            const int t = t0 + u;
+            info[u] = I_NO_HIT;
+            k[u] = k0;
+            base[u] = 0;
+            child_at[u] = 0;
+            if (t < t_end) {
+                while (s_tile_end[kk] <= t) ++kk;
+                k[u] = __builtin_amdgcn_readfirstlane(k0 + kk);
+                const int nv = node_fetch(nl, k[u], lane);
+                if (has_children && lane >= NL_CHILD0 && lane < NL_COUNT && nv >= 0) child_at[u] = D.node_start[nv];
+                base[u] = counter_base(D, level, tbase, q, t, k[u], lane);
+                const int first = (t - LANE(nv, NL_TILE0)) * TILE;
+                const int cnt = min(TILE, LANE(nv, NL_N) - first);
+                if (lane < cnt) info[u] = D.info[(uint32_t)(tbase + t) * TILE + lane];
             }
         }
-        __syncthreads();
+        // phase B: ranks and stores
 #pragma unroll
-        for (int c = 0; c < NCNT; ++c) {
-            if (((want >> c) & 1u) && ((info >> counter_bit(c)) & 1u)) {
-                for (int w = 0; w < wave; ++w) rank[c] += s_wcnt[w][c];
-                rank[c] += (int)gscan(D, level, tbase, q, t, c);
-                if (c != C_SHADE) rank[c] -= (int)D.node_pre[(size_t)k * NCNT + c];
+        for (int u = 0; u < UNROLL_TILES; ++u) {
+            const int t = t0 + u;
+            if (t >= t_end) break;
+            const uint32_t idx = (uint32_t)(tbase + t) * TILE + lane;
+            int rank[NCNT];
+#pragma unroll
+            for (int c = 0; c < NCNT; ++c) {
+                rank[c] = 0;
+                if ((want >> c) & 1u) rank[c] = lanes_below(__ballot(counted(info[u], c))) + LANE(base[u], c);
+            }
+            if (has_children) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if ((info[u] >> (18 + c)) & 1u) D.link[LANE(child_at[u], NL_CHILD0 + c) + rank[c]] = idx;
+                }
+            }
+            if (info[u] & I_SHADE) {
+                const int e = shade_base + rank[C_SHADE];
+                D.list_ray[e] = idx;
+                D.list_node[e] = (uint16_t)k[u];
+                if (D.list_j[0]) D.list_j[0][e] = (uint32_t)rank[C_HIT];
+#pragma unroll
+                for (int l = 0; l < RT_MAX_LIGHTS; ++l)
+                    if ((D.spot_mask >> l) & 1u) D.list_j[1 + l][e] = (uint32_t)rank[C_BEAM0 + l];
             }
         }
-        if (has_children) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if ((info >> (18 + c)) & 1u) D.link[D.node_start[D.node_child[k * 3 + c]] + rank[c]] = idx;
-            }
-        }
-        if (info & I_SHADE) {
-            const int e = shade_base + rank[C_SHADE];
-            D.list_ray[e] = idx;
-            D.list_node[e] = (uint16_t)k;
-            if (D.list_j[0]) D.list_j[0][e] = (uint32_t)rank[C_HIT];
-#pragma unroll
-            for (int l = 0; l < RT_MAX_LIGHTS; ++l)
-                if ((D.spot_mask >> l) & 1u) D.list_j[1 + l][e] = (uint32_t)rank[C_BEAM0 + l];
-        }
-        __syncthreads();
     }
 }
 
@@ -798,11 +946,11 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int64_t entr
 // hits on the shading list ever read their columns, so every uploaded piece of the
 // stream, chunk[0..n) = stream[a..a+n), is scattered straight into the packed layout
 // (entry-major within a sample, so k_surface reads it fully coalesced).
-__global__ __launch_bounds__(TILE) void k_pack(Dev D, const double* chunk, int64_t a, int64_t n) {
+__global__ __launch_bounds__(BLOCK) void k_pack(Dev D, const double* chunk, int64_t a, int64_t n) {
     const SceneConst& sc = *D.sc;
     const int64_t b = a + n;
     const int64_t E = D.pack_E;
-    for (int64_t e = (int64_t)blockIdx.x * TILE + threadIdx.x; e < E; e += (int64_t)gridDim.x * TILE) {
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (int64_t)gridDim.x * BLOCK) {
         const uint32_t info = D.info[D.list_ray[e]];
         const int node = D.list_node[e];
         for (int l = 0; l < D.n_lights; ++l) {
@@ -837,14 +985,14 @@ __global__ __launch_bounds__(TILE) void k_pack(Dev D, const double* chunk, int64
 // ---------------------------------------------------------------------------------------------
 // Lighting for the dense list of hits whose surface colour matters (all levels).
 template <bool LDS, bool MIXED>
-__global__ __launch_bounds__(TILE, MIXED ? RT_MIXED_WAVES : 2) void k_surface(Dev D) {
+__global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(Dev D) {
     __shared__ ShadowSphere s_sh[LDS ? SHADE_LDS_SPHERES : 1];
     __shared__ unsigned s_work[3];
     const int tid = threadIdx.x;
     if (D.flags[0]) return;  // arena overflow: the frame is invalid, the host reports it
     if (tid < 3) s_work[tid] = 0;
     if (LDS) {
-        for (int i = tid; i < D.S; i += TILE) {
+        for (int i = tid; i < D.S; i += BLOCK) {
             const double* g = D.geom + (size_t)i * 4;
             const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
             s_sh[i] = {g[0], g[1], g[2], g[3] * g[3], m[11], m[14] * m[15], m[14] * m[16], m[14] * m[17]};
@@ -854,7 +1002,7 @@ __global__ __launch_bounds__(TILE, MIXED ? RT_MIXED_WAVES : 2) void k_surface(De
     const double eps = D.sc->eps;
     const int total = D.lvl_shade_base[D.n_levels];
     unsigned my_hits = 0, my_samples = 0, my_fallback = 0;
-    for (int e = blockIdx.x * TILE + tid; e < total; e += gridDim.x * TILE) {
+    for (int e = blockIdx.x * BLOCK + tid; e < total; e += gridDim.x * BLOCK) {
         const uint32_t ray = D.list_ray[e];
         const uint32_t info = D.info[ray];
         const int sid = info & I_SID_MASK;
@@ -884,14 +1032,14 @@ __global__ __launch_bounds__(TILE, MIXED ? RT_MIXED_WAVES : 2) void k_surface(De
 
 // Float64 re-evaluation of the hits the mixed-precision pass queued.
 template <bool LDS>
-__global__ __launch_bounds__(TILE) void k_surface_redo(Dev D) {
+__global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
     __shared__ ShadowSphere s_sh[LDS ? SHADE_LDS_SPHERES : 1];
     const int tid = threadIdx.x;
     if (D.flags[0]) return;
     const int total = D.flags[1];
     if (total == 0) return;
     if (LDS) {
-        for (int i = tid; i < D.S; i += TILE) {
+        for (int i = tid; i < D.S; i += BLOCK) {
             const double* g = D.geom + (size_t)i * 4;
             const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
             s_sh[i] = {g[0], g[1], g[2], g[3] * g[3], m[11], m[14] * m[15], m[14] * m[16], m[14] * m[17]};
@@ -899,7 +1047,7 @@ __global__ __launch_bounds__(TILE) void k_surface_redo(Dev D) {
     }
     __syncthreads();
     const double eps = D.sc->eps;
-    for (int i = blockIdx.x * TILE + tid; i < total; i += gridDim.x * TILE) {
+    for (int i = blockIdx.x * BLOCK + tid; i < total; i += gridDim.x * BLOCK) {
         const int64_t e = D.redo_list[i];
         const uint32_t ray = D.list_ray[e];
         const uint32_t info = D.info[ray];
@@ -916,45 +1064,49 @@ __global__ __launch_bounds__(TILE) void k_surface_redo(Dev D) {
 // ---------------------------------------------------------------------------------------------
 // Bottom-up colour combination for one level (reference raytrace.py:155-170); the
 // deepest level runs first.  A ray's colour replaces its surface colour in place.
-__global__ __launch_bounds__(TILE) void k_combine(Dev D, int level) {
+__global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
     __shared__ int s_tile_end[MAX_LEVEL_NODES];
-    __shared__ int s_wcnt[4][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (D.flags[0]) return;
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
-    for (int i = tid; i < nn; i += TILE) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
+    for (int i = tid; i < nn; i += BLOCK) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = (nt + NB - 1) / NB;
-    const int t_begin = blockIdx.x * q;
+    const int q = (nt + NW - 1) / NW;
+    const int wid = blockIdx.x * WPB + wave;
+    const int t_begin = wid * q;
     const int t_end = min(nt, t_begin + q);
     __syncthreads();
     const SceneConst& sc = *D.sc;
     const V3 bg = ld3(sc.bg);
     const bool has_children = level + 1 < D.n_levels;
 
+    int kk = (t_begin < t_end) ? find_node(s_tile_end, nn, t_begin) : 0;
+    const NodeLane nl = node_lane(D, lane);
     for (int t = t_begin; t < t_end; ++t) {
-        const int k = k0 + find_node(s_tile_end, nn, t);
+        while (s_tile_end[kk] <= t) ++kk;
+        const int k = __builtin_amdgcn_readfirstlane(k0 + kk);
         const int first = (t - D.node_tile0[k]) * TILE;
         const int cnt = min(TILE, D.node_n[k] - first);
-        const uint32_t idx = (uint32_t)(tbase + t) * TILE + tid;
-        const bool valid = tid < cnt;
-        const uint32_t info = valid ? D.info[idx] : 0u;
+        const uint32_t idx = (uint32_t)(tbase + t) * TILE + lane;
+        const uint32_t info = (lane < cnt) ? D.info[idx] : I_NO_HIT;
 
-        int rank[3] = {0, 0, 0};
-        if (has_children) {
+        uint32_t slot[3] = {0, 0, 0};   // arena index of the ray's child of each kind
+        const bool reads_child = ((info & I_LIVE_TI) && (info & (I_CHILD_T | I_CHILD_I))) ||
+                                 ((info & I_LIVE_R) && (info & I_CHILD_R));
+        if (has_children && __ballot(reads_child) != 0) {
+            const int nv = node_fetch(nl, k, lane);
+            uint32_t child_at = 0;
+            if (lane >= NL_CHILD0 && lane < NL_COUNT && nv >= 0) child_at = D.node_start[nv];
+            const int base = counter_base(D, level, tbase, q, t, k, lane);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                unsigned long long mk = __ballot(((info >> (18 + c)) & 1u) != 0);
-                if (lane == 0) s_wcnt[wave][c] = __popcll(mk);
-                rank[c] = lanes_below(mk);
-            }
-            __syncthreads();
+            for (int c = 0; c < 3; ++c)
+                slot[c] = LANE(child_at, NL_CHILD0 + c) + LANE(base, c) + lanes_below(__ballot(((info >> (18 + c)) & 1u) != 0));
         }
 
-        if (valid) {
+        if (info & I_LIVE) {   // nobody reads the colour of a ray whose weight in the pixel is zero
             V3 col = bg;
-            if (info & I_HIT) {
+            if (is_hit(info)) {
                 const int sid = info & I_SID_MASK;
                 const bool inside = info & I_INSIDE;
                 const double* m = D.mat + (size_t)sid * RT_MAT_WIDTH;
@@ -963,12 +1115,8 @@ __global__ __launch_bounds__(TILE) void k_combine(Dev D, int level) {
                 V3 surf = {0, 0, 0}, refr = {0, 0, 0}, refl = {0, 0, 0};
                 if (info & I_SHADE) surf = {D.cr[idx], D.cg[idx], D.cb[idx]};
                 if ((info & I_LIVE_TI) && (info & (I_CHILD_T | I_CHILD_I))) {
-                    const int c = (info & I_CHILD_T) ? C_T : C_I;
-                    int r = rank[c];
-                    for (int w = 0; w < wave; ++w) r += s_wcnt[w][c];
-                    r += (int)(gscan(D, level, tbase, q, t, c) - D.node_pre[(size_t)k * NCNT + c]);
-                    const uint32_t slot = D.node_start[D.node_child[k * 3 + c]] + r;
-                    refr = {D.cr[slot], D.cg[slot], D.cb[slot]};
+                    const uint32_t sl = (info & I_CHILD_T) ? slot[C_T] : slot[C_I];
+                    refr = {D.cr[sl], D.cg[sl], D.cb[sl]};
                     if ((info & I_CHILD_T) && !inside) {
                         // absorption inside the entered sphere (reference raytrace.py:119-120)
                         const double through = D.dist[idx];
@@ -979,21 +1127,17 @@ __global__ __launch_bounds__(TILE) void k_combine(Dev D, int level) {
                     }
                 }
                 if ((info & I_LIVE_R) && (info & I_CHILD_R)) {
-                    int r = rank[C_R];
-                    for (int w = 0; w < wave; ++w) r += s_wcnt[w][C_R];
-                    r += (int)(gscan(D, level, tbase, q, t, C_R) - D.node_pre[(size_t)k * NCNT + C_R]);
-                    const uint32_t slot = D.node_start[D.node_child[k * 3 + C_R]] + r;
-                    refl = {D.cr[slot], D.cg[slot], D.cb[slot]};
+                    const uint32_t sl = slot[C_R];
+                    refl = {D.cr[sl], D.cg[sl], D.cb[sl]};
                 }
                 col = clip01(((1 - tr) * (1 - A)) * surf + (tr * (1 - A)) * refr + A * refl);
             }
             D.cr[idx] = col.x; D.cg[idx] = col.y; D.cb[idx] = col.z;
             if (level == 0) {
-                double* out = D.image + (size_t)(first + tid) * 3;
+                double* out = D.image + (size_t)(first + lane) * 3;
                 out[0] = col.x; out[1] = col.y; out[2] = col.z;
             }
         }
-        if (has_children) __syncthreads();
     }
 }
 
