@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--scenes", nargs="*", default=SCENES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-frames", action="store_true",
+                    help="one private stream per frame: frames overlap (higher throughput, per-kernel times inflate)")
     args = ap.parse_args()
 
     import torch
@@ -81,12 +83,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local_rank)
     W, H = args.width, args.height
+    # every kernel of every frame goes to this one stream (so do the tile transfers), which
+    # keeps the per-kernel event timings free of overlap
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
 
     # ---- set-up: geometry once, then draw + upload the disk-light samples -------------------
     t_setup = time.perf_counter()
     jobs = []
     for name in args.scenes:
-        job = FrameJob(name, W, H, device=local_rank, rank=rank, world=world, group=group)
+        job = FrameJob(name, W, H, device=local_rank, rank=rank, world=world, group=group,
+                       private_stream=args.overlap_frames)
         np.random.seed(0)
         job.prepare()            # first geometry pass, row split, samples resident in HBM
         jobs.append(job)

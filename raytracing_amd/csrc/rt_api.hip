@@ -106,7 +106,7 @@ struct RtContext {
     DevBuf<SceneConst> sc;
     DevBuf<int32_t> node_a, node_b, node_branch, node_child, level_start;
     DevBuf<int32_t> node_n, node_nglobal, node_hits, node_beam, node_tile0, node_ntiles, lvl_ntiles, lvl_tilebase, flags;
-    DevBuf<uint32_t> node_start, node_pre, tile_run, blk_tot;
+    DevBuf<uint32_t> node_start, node_pre, tile_run, blk_tot, wave_off;
     DevBuf<double> px, py, pz, dx, dy, dz, A, dist, cr, cg, cb;
     DevBuf<uint32_t> info, link, list_ray, redo_list, list_j[1 + RT_MAX_LIGHTS];
     DevBuf<uint16_t> list_node;
@@ -140,7 +140,7 @@ struct RtContext {
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
         D.node_n = node_n.p; D.node_nglobal = node_nglobal.p; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
         D.node_tile0 = node_tile0.p; D.node_ntiles = node_ntiles.p; D.node_start = node_start.p; D.node_pre = node_pre.p;
-        D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p;
+        D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p; D.wave_off = wave_off.p;
         D.flags = flags.p; D.work = work.p;
         D.px = px.p; D.py = py.p; D.pz = pz.p; D.dx = dx.p; D.dy = dy.p; D.dz = dz.p; D.A = A.p; D.dist = dist.p;
         D.info = info.p; D.link = link.p; D.cr = cr.p; D.cg = cg.p; D.cb = cb.p;
@@ -278,7 +278,7 @@ void rt_destroy(RtContext* ctx) {
     ctx->level_start.release(); ctx->node_n.release(); ctx->node_nglobal.release(); ctx->node_hits.release();
     ctx->node_beam.release(); ctx->node_tile0.release(); ctx->node_ntiles.release(); ctx->lvl_ntiles.release();
     ctx->lvl_tilebase.release(); ctx->flags.release(); ctx->node_start.release(); ctx->node_pre.release();
-    ctx->tile_run.release(); ctx->blk_tot.release();
+    ctx->tile_run.release(); ctx->blk_tot.release(); ctx->wave_off.release();
     ctx->px.release(); ctx->py.release(); ctx->pz.release(); ctx->dx.release(); ctx->dy.release(); ctx->dz.release();
     ctx->A.release(); ctx->dist.release(); ctx->cr.release(); ctx->cg.release(); ctx->cb.release();
     ctx->info.release(); ctx->link.release(); ctx->list_ray.release(); ctx->redo_list.release(); ctx->list_node.release(); ctx->lvl_shade_base.release();
@@ -354,7 +354,8 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     HIP_TRY(ctx->node_start.ensure(K)); HIP_TRY(ctx->node_pre.ensure(K * NCNT));
     HIP_TRY(ctx->lvl_ntiles.ensure(tree.n_levels())); HIP_TRY(ctx->lvl_tilebase.ensure(tree.n_levels()));
     HIP_TRY(ctx->lvl_shade_base.ensure(tree.n_levels() + 1));
-    HIP_TRY(ctx->blk_tot.ensure((size_t)tree.n_levels() * NW * NCNT));
+    HIP_TRY(ctx->blk_tot.ensure((size_t)tree.n_levels() * NB * NCNT));
+    HIP_TRY(ctx->wave_off.ensure((size_t)tree.n_levels() * NW * NCNT));
     HIP_TRY(ctx->flags.ensure(4));
     HIP_TRY(ctx->work.ensure(4));
     HIP_TRY(ctx->sample_off.ensure(K * RT_MAX_LIGHTS));

@@ -76,7 +76,8 @@ struct Dev {
     int32_t* lvl_ntiles;    // [n_levels]
     int32_t* lvl_tilebase;  // [n_levels] first tile of the level in the arena
     uint32_t* tile_run;     // [tiles][NCNT] running counter value inside the producing wave
-    uint32_t* blk_tot;      // [n_levels][NW][NCNT] per-wave totals, turned into prefixes by k_scan
+    uint32_t* blk_tot;      // [n_levels][NCNT][NB] per-workgroup totals, turned into prefixes by k_scan
+    uint32_t* wave_off;     // [n_levels][NCNT][NW] counter value at a wave's first tile relative to its workgroup
     int32_t* flags;         // [0] overflow, [1] entries queued for float64 re-evaluation
     unsigned long long* work;  // [0] hits shaded, [1] light samples evaluated (cleared by k_init)
     // ray arena (structure of arrays, one slot per ray)

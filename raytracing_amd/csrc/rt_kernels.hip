@@ -24,6 +24,9 @@
 // order operation by operation; only explicit fma() calls fuse.
 #include "rt_internal.h"
 
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 4   // waves per SIMD requested for k_trace
+#endif
 #ifndef RT_MIXED_WAVES
 #define RT_MIXED_WAVES 2   // waves per SIMD requested for the mixed-precision surface kernel
 #endif
@@ -66,7 +69,9 @@ __device__ __forceinline__ int find_node(const int* tile_end, int nn, int t) {
 
 // Level-wide running value of counter c at the start of tile t (relative tile index).
 __device__ __forceinline__ unsigned gscan(const Dev& D, int level, int tbase, int q, int t, int c) {
-    return D.blk_tot[((size_t)level * NCNT + c) * NW + t / q] + D.tile_run[(size_t)(tbase + t) * NCNT + c];
+    const int w = t / q;   // the wave that produced the tile
+    return D.blk_tot[((size_t)level * NCNT + c) * NB + w / WPB] + D.wave_off[((size_t)level * NCNT + c) * NW + w] +
+           D.tile_run[(size_t)(tbase + t) * NCNT + c];
 }
 
 // The facts about a node that the tile loops need are fetched with ONE vector load per tile:
@@ -101,7 +106,9 @@ __device__ __forceinline__ int node_fetch(const NodeLane& nl, int k, int lane) {
 // first tile of node k (not for the shade counter, whose list is level-wide).
 __device__ __forceinline__ int counter_base(const Dev& D, int level, int tbase, int q, int t, int k, int lane) {
     if (lane >= NCNT) return 0;
-    int v = (int)(D.blk_tot[((size_t)level * NCNT + lane) * NW + t / q] + D.tile_run[(size_t)(tbase + t) * NCNT + lane]);
+    const int w = t / q;
+    int v = (int)(D.blk_tot[((size_t)level * NCNT + lane) * NB + w / WPB] + D.wave_off[((size_t)level * NCNT + lane) * NW + w] +
+                  D.tile_run[(size_t)(tbase + t) * NCNT + lane]);
     if (lane != C_SHADE) v -= (int)D.node_pre[(size_t)k * NCNT + lane];
     return v;
 }
@@ -198,7 +205,7 @@ __global__ void k_init(Dev D) {
 // Nearest hit + hit record for one level.  Every wave walks its own run of tiles; the
 // only workgroup-wide steps are staging the spheres in LDS.
 template <int SPH_CHUNK>   // spheres staged in LDS per pass (a small value leaves room for more workgroups)
-__global__ __launch_bounds__(BLOCK) void k_trace(Dev D, int level) {
+__global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int level) {
     __shared__ int s_tile_end[MAX_LEVEL_NODES];
     __shared__ double s_sph[SPH_CHUNK][4];
 
@@ -445,7 +452,16 @@ __global__ __launch_bounds__(BLOCK) void k_trace(Dev D, int level) {
             run += mine;
         }
     }
-    if (lane < NCNT) D.blk_tot[((size_t)level * NCNT + lane) * NW + wid] = run;
+    // totals: per workgroup for k_scan, plus every wave's offset inside its workgroup
+    __shared__ unsigned s_wtot[WPB][NCNT];
+    if (lane < NCNT) s_wtot[wave][lane] = run;
+    __syncthreads();
+    if (lane < NCNT) {
+        unsigned off = 0;
+        for (int w = 0; w < wave; ++w) off += s_wtot[w][lane];
+        D.wave_off[((size_t)level * NCNT + lane) * NW + wid] = off;
+        if (wave == WPB - 1) D.blk_tot[((size_t)level * NCNT + lane) * NB + blockIdx.x] = off + run;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,51 +473,51 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
     const int tbase = D.lvl_tilebase[level];
     const int q = max(1, (nt + NW - 1) / NW);
 
-    // 1. exclusive scan of the per-wave totals (stored counter-major), one wave per counter;
-    //    every lane owns a run of consecutive entries
+    // 1. exclusive scan of the per-workgroup totals (stored counter-major), one wave per
+    //    counter; every lane owns a run of consecutive entries and has all its loads in flight
     if (wave < NCNT) {
-        constexpr int PER = NW / 64;
-        uint32_t* base = D.blk_tot + ((size_t)level * NCNT + wave) * NW + lane * PER;
-        const uint4* src = reinterpret_cast<const uint4*>(base);
+        constexpr int PER = NB / 64;
+        uint32_t* base = D.blk_tot + ((size_t)level * NCNT + wave) * NB + lane * PER;
+        uint4 v[PER / 4];
         unsigned sum = 0;
-#pragma unroll 8
-        for (int i = 0; i < PER / 4; ++i) {
-            const uint4 v = src[i];
-            sum += v.x + v.y + v.z + v.w;
-        }
+#pragma unroll
+        for (int i = 0; i < PER / 4; ++i) v[i] = reinterpret_cast<const uint4*>(base)[i];
+#pragma unroll
+        for (int i = 0; i < PER / 4; ++i) sum += v[i].x + v[i].y + v[i].z + v[i].w;
         unsigned incl = sum;
         for (int off = 1; off < 64; off <<= 1) {
             unsigned up = __shfl_up(incl, off);
             if (lane >= off) incl += up;
         }
         unsigned running = incl - sum;
-        uint4* dst = reinterpret_cast<uint4*>(base);
-#pragma unroll 8
+#pragma unroll
         for (int i = 0; i < PER / 4; ++i) {
-            const uint4 v = src[i];
             uint4 o;
-            o.x = running; running += v.x;
-            o.y = running; running += v.y;
-            o.z = running; running += v.z;
-            o.w = running; running += v.w;
-            dst[i] = o;
+            o.x = running; running += v[i].x;
+            o.y = running; running += v[i].y;
+            o.z = running; running += v[i].z;
+            o.w = running; running += v[i].w;
+            reinterpret_cast<uint4*>(base)[i] = o;
         }
         if (lane == 63) s_grand[wave] = incl;
     }
     __syncthreads();
 
-    // 2. per-node prefix and totals
+    // 2. per-node prefix and totals: the running value of every counter at the node's first
+    //    tile goes to LDS, so that a node's total is the difference to the next node's value
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
+    __shared__ unsigned s_pre[(MAX_LEVEL_NODES + 1) * NCNT];
+    for (int i = tid; i < nn * NCNT; i += 1024) {
+        const int kk = i / NCNT, c = i % NCNT;
+        const int T0 = D.node_tile0[k0 + kk];
+        s_pre[i] = (T0 < nt) ? gscan(D, level, tbase, q, T0, c) : s_grand[c];
+    }
+    if (tid < NCNT) s_pre[nn * NCNT + tid] = s_grand[tid];
+    __syncthreads();
     for (int i = tid; i < nn * NCNT; i += 1024) {
         const int kk = i / NCNT, c = i % NCNT, k = k0 + kk;
-        const int T0 = D.node_tile0[k];
-        const unsigned s = (T0 < nt) ? gscan(D, level, tbase, q, T0, c) : s_grand[c];
-        unsigned e = s_grand[c];
-        if (kk + 1 < nn) {
-            const int T1 = D.node_tile0[k + 1];
-            if (T1 < nt) e = gscan(D, level, tbase, q, T1, c);
-        }
-        const unsigned tot = e - s;
+        const unsigned s = s_pre[i];
+        const unsigned tot = s_pre[i + NCNT] - s;
         D.node_pre[(size_t)k * NCNT + c] = s;
         if (c < 3) {
             const int child = D.node_child[k * 3 + c];

@@ -357,7 +357,7 @@ class FrameJob:
     """A benchmark frame on the GPUs of this process group: set-up once, then
     ``step()`` re-renders it with the samples already resident in HBM."""
 
-    def __init__(self, scene_name, width, height, device=0, rank=0, world=1, group=None):
+    def __init__(self, scene_name, width, height, device=0, rank=0, world=1, group=None, private_stream=False):
         import torch
         from . import _native
         from .Scenes.scenes import build_scene
@@ -367,9 +367,15 @@ class FrameJob:
         self.comm = Comm(group, self.device if world > 1 else None)
         scene = build_scene(scene_name, width, height)
         params = RenderParams(width=width, height=height)
-        # one private stream per frame on a single GPU (frames overlap); torch's current
-        # stream when tiles are exchanged, so the transfers are ordered after the kernels
-        stream = torch.cuda.current_stream(self.device).cuda_stream if world > 1 else None
+        # torch's current stream by default (kernels of successive frames run one after the
+        # other and tile transfers are ordered after the kernels); a private stream per frame
+        # lets the small launches of different frames overlap on a single GPU
+        if private_stream and world == 1:
+            stream = None
+        else:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            if not stream:   # the legacy default stream has handle 0, which rt_create reads as "make your own"
+                raise RuntimeError("run FrameJob under `with torch.cuda.stream(torch.cuda.Stream()):`")
         self.ctx = _native.Context(device, stream)
         self.r = ShardedRenderer(scene, params, self.comm, self.ctx)
         self.width, self.height = width, height
