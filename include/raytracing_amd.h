@@ -181,6 +181,16 @@ int rt_trace_level(RtContext *ctx, int32_t level);
 int rt_get_level_batches(RtContext *ctx, int32_t level, int64_t *n_local /* [nodes of level] */);
 int rt_set_global_batches(RtContext *ctx, int32_t level, const int64_t *n_global);
 
+/* Alternative to the two calls above that needs no host round trip: keep the
+ * whole-image batch sizes in caller-owned DEVICE memory, int32[n_nodes] (for
+ * example a torch tensor).  rt_trace_level(l) then leaves the LOCAL sizes of
+ * level l+1 in device_batches[level_start[l+1] .. level_start[l+2]) and reads
+ * the sizes of level l from the same array; between the two calls the caller
+ * sums that slice over all GPUs in place with a stream-ordered collective
+ * (RCCL all-reduce on the context's stream).  NULL switches back to the
+ * context's own array.  Call after rt_set_scene. */
+int rt_set_batch_buffer(RtContext *ctx, int32_t *device_batches);
+
 /* Per-node results of the geometry phase (synchronises):
  * batch[k] local rays of node k, hits[k] local hits, beam[k][l] local hits
  * inside spotlight l's beam.  Arrays may be NULL. */

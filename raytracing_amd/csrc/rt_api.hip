@@ -119,6 +119,7 @@ struct RtContext {
     DevBuf<int64_t> sample_off;
     DevBuf<unsigned long long> work;
     double* user_image = nullptr;
+    int32_t* user_batches = nullptr;
 
     int64_t npix = 0;
     int row0 = 0;
@@ -138,7 +139,7 @@ struct RtContext {
         D.geom = geom.p; D.mat = mat.p; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
         D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
-        D.node_n = node_n.p; D.node_nglobal = node_nglobal.p; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
+        D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
         D.node_tile0 = node_tile0.p; D.node_ntiles = node_ntiles.p; D.node_start = node_start.p; D.node_pre = node_pre.p;
         D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p; D.wave_off = wave_off.p;
         D.flags = flags.p; D.work = work.p;
@@ -368,6 +369,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     ctx->disk_lights = disk;
     ctx->spot_mask = spot_mask;
     for (auto& b : ctx->list_j) b.release();   // sized per frame for the lights of this scene
+    ctx->user_batches = nullptr;
     ctx->have_scene = true;
     ctx->frame_begun = ctx->geometry_done = ctx->layout_set = ctx->shaded = false;
     return RT_OK;
@@ -477,7 +479,8 @@ int rt_set_global_batches(RtContext* ctx, int32_t level, const int64_t* n_global
         if (n_global[i] < 0 || n_global[i] > 0x7FFFFFFF) return fail(RT_ERR_INVALID, "batch size out of range");
         tmp[i] = (int32_t)n_global[i];
     }
-    HIP_TRY(hipMemcpyAsync(ctx->node_nglobal.p + k0, tmp.data(), nn * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync((ctx->user_batches ? ctx->user_batches : ctx->node_nglobal.p) + k0, tmp.data(), nn * 4,
+                           hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -569,6 +572,13 @@ int rt_shade(RtContext* ctx) {
     return RT_OK;
 }
 
+int rt_set_batch_buffer(RtContext* ctx, int32_t* device_batches) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->have_scene) return fail(RT_ERR_STATE, "rt_set_scene has not been called");
+    ctx->user_batches = device_batches;
+    return RT_OK;
+}
+
 int rt_set_output(RtContext* ctx, void* device_rgb) {
     if (int rc = use_device(ctx)) return rc;
     if (!ctx->frame_begun) return fail(RT_ERR_STATE, "rt_begin_frame has not been called");
@@ -619,7 +629,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     unsigned long long work[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(work, ctx->work.p, sizeof work, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(n.data(), ctx->node_n.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ng.data(), ctx->node_nglobal.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ng.data(), ctx->user_batches ? ctx->user_batches : ctx->node_nglobal.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(h.data(), ctx->node_hits.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(nt.data(), ctx->lvl_ntiles.p, Lv * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(tb.data(), ctx->lvl_tilebase.p, Lv * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -165,6 +165,7 @@ class ShardedRenderer:
         self.bounds = None
         self.arena_rays = 0
         self.rays_per_pixel = 24
+        self.batch_tensor = None      # torch int32 tensor on the GPU holding whole-image batch sizes
         self.global_hits = self.global_beam = self.global_batch = None
         self.local_hits = self.local_beam = self.local_batch = None
         self.samples_total = 0
@@ -209,6 +210,8 @@ class ShardedRenderer:
             rows, cost = self.probe_costs()
             self.bounds = split_rows(self.params.height, self.comm.world, rows, cost)
         self.ctx.set_scene(self.flat, self.params, self.tree)
+        if self.batch_tensor is not None:
+            self.ctx.set_batch_buffer(self.batch_tensor.data_ptr())
         return self.bounds
 
     @property
@@ -230,6 +233,16 @@ class ShardedRenderer:
         ctx, comm = self.ctx, self.comm
         if comm.world == 1:
             ctx.trace_geometry()
+            return
+        if self.batch_tensor is not None:
+            # batch sizes stay on the GPU: the all-reduce is queued on the kernels' stream
+            # between two levels and nothing waits on the host
+            import torch.distributed as dist
+            ls = self.tree.level_start
+            for level in range(self.tree.n_levels):
+                if level > 0:
+                    dist.all_reduce(self.batch_tensor[int(ls[level]):int(ls[level + 1])], group=comm.group)
+                ctx.trace_level(level)
             return
         for level in range(self.tree.n_levels):
             if level > 0:
@@ -378,6 +391,8 @@ class FrameJob:
                 raise RuntimeError("run FrameJob under `with torch.cuda.stream(torch.cuda.Stream()):`")
         self.ctx = _native.Context(device, stream)
         self.r = ShardedRenderer(scene, params, self.comm, self.ctx)
+        if world > 1:
+            self.r.batch_tensor = torch.zeros(self.r.tree.n_nodes, dtype=torch.int32, device=self.device)
         self.width, self.height = width, height
         self.full = self.tile = None
 

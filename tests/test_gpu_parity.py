@@ -202,3 +202,28 @@ def test_call_order_errors():
         r.ctx.trace_geometry()
         with pytest.raises(_native.RtError):
             r.ctx.shade()                   # disk light samples missing
+
+
+def test_batch_sizes_in_caller_owned_device_memory(golden_dir):
+    """rt_set_batch_buffer: the whole-image batch sizes live in a torch tensor, the
+    levels are traced one by one and nothing is copied through the host (on several
+    GPUs an all-reduce of the level's slice sits between two levels)."""
+    import torch
+    g = _load(golden_dir, "images_160x90.npz")
+    scene = build_scene("example_3", 160, 90)
+    with Renderer(scene, precision="f64") as r:
+        buf = torch.zeros(r.tree.n_nodes, dtype=torch.int32, device="cuda")
+        r.ctx.set_batch_buffer(buf.data_ptr())
+        r.begin_rows(0, 90)
+        for level in range(r.tree.n_levels):
+            r.ctx.trace_level(level)
+        batch, hits, beam = r.ctx.node_counts()
+        r.shade()
+        img = r.image().reshape(90, 160, 3)
+        assert np.array_equal(buf.cpu().numpy(), batch)          # one GPU: global == local
+        # shrinking a batch below the limit in the buffer kills that node on the next frame
+        assert np.abs(img - g["example_3_image"]).max() <= TOL
+        r.ctx.set_batch_buffer(None)
+        r.ctx.trace_geometry()
+        r.shade()
+        assert np.array_equal(r.image().reshape(90, 160, 3), img)
