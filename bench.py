@@ -34,7 +34,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 SCENES = ["example_1", "example_2", "example_3", "example_4"]
-FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (half the 157.3 TF packed-FP32 vector peak)
+FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X vector FP32 with packed FMA (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (half the packed-FP32 figure)
 HBM_PEAK_GBS = 8000.0
 # algorithmic FLOP model: per (ray, sphere) nearest-hit test, per hit, per (hit, light sample)
 # and per (shadow ray, sphere) test
@@ -72,6 +73,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--scenes", nargs="*", default=SCENES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["mixed", "f64"], default="mixed")
     ap.add_argument("--overlap-frames", action="store_true",
                     help="one private stream per frame: frames overlap (higher throughput, per-kernel times inflate)")
     args = ap.parse_args()
@@ -93,7 +95,7 @@ def main():
     jobs = []
     for name in args.scenes:
         job = FrameJob(name, W, H, device=local_rank, rank=rank, world=world, group=group,
-                       private_stream=args.overlap_frames)
+                       private_stream=args.overlap_frames, precision=args.precision)
         np.random.seed(0)
         job.prepare()            # first geometry pass, row split, samples resident in HBM
         jobs.append(job)
@@ -146,29 +148,52 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = rays / (elapsed / args.steps) / 1e6
 
-    # dominant kernel = the kind with the largest accumulated device time on rank 0
-    dominant = max(prof, key=lambda k: prof[k]["ms"])
-    local = [job.local_stats() for job in jobs]      # this rank's share, what its kernels executed
-    flops = {
-        "trace": sum(F_ISECT * s["rays"] * s["spheres"] + F_HIT * s["hits"] for s in local),
-        "surface": sum((F_LIGHT + F_SHADOW * s["spheres"]) * s["shaded_samples"] for s in local),
+    # ---- rooflines (rank 0's share of the work, its own kernel times) -------------------------
+    # Algorithmic work per step from the device counters:
+    #   k_trace   reads link (4 B) + parent info, hit point, direction (52 B) per non-primary ray,
+    #             writes info (4 B) per ray, 48 B per stored hit record, 16 B per live hit and the
+    #             per-tile counters (52 B per 64 rays);   FLOPs 22 per (ray, sphere) + 100 per hit
+    #   k_surface reads 52 B per shaded hit + 16 B per disk-light sample, writes 24 B per shaded hit;
+    #             FLOPs (50 + 24 * spheres) per light sample
+    local = [job.local_stats() for job in jobs]
+    sec = {k: v["ms"] * 1e-3 / args.steps for k, v in prof.items()}
+    trace_bytes = sum(56 * (s["rays"] - s["pixels"]) + (4 + 52 / 64) * s["rays"] + 48 * s["stored_records"]
+                      + 16 * s["live_hits"] for s in local)
+    trace_flops = sum(F_ISECT * s["rays"] * s["spheres"] + F_HIT * s["hits"] for s in local)
+    disk_samples = sum(s["shaded_samples"] - s["shaded_hits"] * sum(1 for k, _ in s["lights"] if k == 0)
+                       for s in local if any(k != 0 for k, _ in s["lights"]))
+    surf_bytes = sum(76 * s["shaded_hits"] for s in local) + 16 * disk_samples
+    surf_flops = sum((F_LIGHT + F_SHADOW * s["spheres"]) * s["shaded_samples"] for s in local)
+    mixed = all(job.precision == "mixed" for job in jobs)
+
+    def roof(kind, bound, work, peak, unit, extra):
+        t = sec.get(kind, 0.0)
+        launches = prof[kind]["launches"] / args.steps if kind in prof else 0
+        if not t or not launches:
+            return None
+        achieved = work / t / (1e9 if unit == "GB/s" else 1e12)
+        r = {"kernel": "k_" + kind, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+             "frac": achieved / peak, "traffic": None, "launches_per_step": launches,
+             "avg_launch_ms": t * 1e3 / launches, "work_per_step": work}
+        r.update(extra)
+        return r
+
+    rooflines = {
+        "trace": roof("trace", "hbm", trace_bytes, HBM_PEAK_GBS, "GB/s",
+                      {"model": "algorithmic bytes", "flops_per_step": trace_flops, "dtype": "f64"}),
+        "surface": roof("surface", "valu", surf_flops, FP32_VALU_PEAK_TFLOPS if mixed else FP64_VALU_PEAK_TFLOPS,
+                        "TFLOP/s", {"model": "algorithmic FLOPs", "bytes_per_step": surf_bytes,
+                                    "dtype": "f32 samples, f64 decisions re-checked" if mixed else "f64"}),
     }
-    roofline = None
-    if dominant in flops and prof[dominant]["launches"]:
-        per_launch_ms = prof[dominant]["ms"] / prof[dominant]["launches"]
-        launches_per_step = prof[dominant]["launches"] / args.steps
-        tflops = flops[dominant] / launches_per_step / (per_launch_ms * 1e-3) / 1e12
-        roofline = {"kernel": "k_" + dominant, "bound": "valu", "dtype": "f64",
-                    "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": None,
-                    "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step,
-                    "flops_per_step": flops[dominant]}
+    dominant = max((k for k in rooflines if rooflines[k]), key=lambda k: sec.get(k, 0.0), default=None)
+    roofline = rooflines.get(dominant)
 
     out = {
         "metric": "Mrays/s (primary+secondary) at 3840x2160 example scenes",
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64 geometry + f32 disk-light samples (f64 re-check)" if mixed else "f64", "data": "synthetic",
         "config": {"workload": f"{'+'.join(args.scenes)} at {W}x{H}, depths (3,5), example_4 with 30 disk samples/hit "
                                f"(seed 0); one step = all frames, geometry + shading",
                    "rays_per_step": rays, "hits_per_step": hits, "shadow_rays_per_step": shadow_rays,
@@ -176,6 +201,7 @@ def main():
         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
         "setup_s": setup_s,
         "roofline": roofline,
+        "rooflines": rooflines,
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

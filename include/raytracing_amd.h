@@ -112,6 +112,9 @@ typedef struct RtCounters {
     int64_t shaded_samples;  /* light samples evaluated for them = shadow rays cast    */
     int64_t fallback_samples;/* disk-light samples the float32 evaluation could not
                                 certify and re-evaluated in float64 (mixed precision)  */
+    int64_t stored_records;  /* hits whose record (hit point, direction) was stored: hits
+                                with a child ray or a surface colour that matters      */
+    int64_t live_hits;       /* hits with non-zero weight in their pixel               */
     int64_t arena_rays_used; /* ray slots used, including tile padding                 */
     int64_t arena_capacity;  /* ray slots allocated                                    */
     int32_t n_nodes;         /* nodes of the static ray tree                           */

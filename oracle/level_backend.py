@@ -157,7 +157,8 @@ class CpuContext:
     def counters(self):
         small = self.params.small_num
         return dict(pixels=self.npix, rays=int(self.n_local[self.n_global >= small].sum()),
-                    hits=int(self.hits.sum()), shaded_hits=0, shaded_samples=0,
+                    hits=int(self.hits.sum()), shaded_hits=0, shaded_samples=0, fallback_samples=0,
+                    stored_records=0, live_hits=0,
                     arena_rays_used=self.used, arena_capacity=self.arena_rays,
                     n_nodes=self.n_nodes, n_levels=self.n_levels, overflow=self.overflow)
 

@@ -59,6 +59,7 @@ class RtParams(C.Structure):
 class RtCounters(C.Structure):
     _fields_ = [("pixels", C.c_int64), ("rays", C.c_int64), ("hits", C.c_int64),
                 ("shaded_hits", C.c_int64), ("shaded_samples", C.c_int64), ("fallback_samples", C.c_int64),
+                ("stored_records", C.c_int64), ("live_hits", C.c_int64),
                 ("arena_rays_used", C.c_int64), ("arena_capacity", C.c_int64),
                 ("n_nodes", C.c_int32), ("n_levels", C.c_int32), ("overflow", C.c_int32), ("reserved", C.c_int32)]
 

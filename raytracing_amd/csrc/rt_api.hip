@@ -358,7 +358,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     HIP_TRY(ctx->blk_tot.ensure((size_t)tree.n_levels() * NB * NCNT));
     HIP_TRY(ctx->wave_off.ensure((size_t)tree.n_levels() * NW * NCNT));
     HIP_TRY(ctx->flags.ensure(4));
-    HIP_TRY(ctx->work.ensure(4));
+    HIP_TRY(ctx->work.ensure(8));
     HIP_TRY(ctx->sample_off.ensure(K * RT_MAX_LIGHTS));
 
     ctx->tree = std::move(tree);
@@ -626,7 +626,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     const int K = ctx->tree.n_nodes(), Lv = ctx->tree.n_levels();
     std::vector<int32_t> n(K), ng(K), h(K), nt(Lv), tb(Lv);
     int32_t flag = 0;
-    unsigned long long work[3] = {0, 0, 0};
+    unsigned long long work[5] = {0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(work, ctx->work.p, sizeof work, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(n.data(), ctx->node_n.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ng.data(), ctx->user_batches ? ctx->user_batches : ctx->node_nglobal.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -644,6 +644,8 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     out->shaded_hits = (int64_t)work[0];
     out->shaded_samples = (int64_t)work[1];
     out->fallback_samples = (int64_t)work[2];
+    out->stored_records = (int64_t)work[3];
+    out->live_hits = (int64_t)work[4];
     out->arena_rays_used = (int64_t)(tb[Lv - 1] + nt[Lv - 1]) * TILE;
     out->arena_capacity = ctx->arena_rays;
     out->n_nodes = K;

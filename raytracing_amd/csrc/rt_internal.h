@@ -79,7 +79,8 @@ struct Dev {
     uint32_t* blk_tot;      // [n_levels][NCNT][NB] per-workgroup totals, turned into prefixes by k_scan
     uint32_t* wave_off;     // [n_levels][NCNT][NW] counter value at a wave's first tile relative to its workgroup
     int32_t* flags;         // [0] overflow, [1] entries queued for float64 re-evaluation
-    unsigned long long* work;  // [0] hits shaded, [1] light samples evaluated (cleared by k_init)
+    unsigned long long* work;  // [0] hits shaded, [1] light samples evaluated, [2] samples queued for float64,
+                               // [3] hit records stored, [4] live hits (cleared by k_init)
     // ray arena (structure of arrays, one slot per ray)
     double *px, *py, *pz;   // hit point
     double *dx, *dy, *dz;   // ray direction

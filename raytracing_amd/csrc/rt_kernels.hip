@@ -190,6 +190,8 @@ __global__ void k_init(Dev D) {
         D.work[0] = 0;
         D.work[1] = 0;
         D.work[2] = 0;
+        D.work[3] = 0;
+        D.work[4] = 0;
         if ((uint32_t)nt > D.cap_tiles) {
             D.flags[0] = 1;
             nt = 0;
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
     const int wid = blockIdx.x * WPB + wave;
     const int t_first = wid * q;
     unsigned run = 0;  // lanes 0..NCNT-1: running counters of this wave
+    unsigned n_rec = 0, n_live = 0;   // hit records / (A, path length) pairs this wave stored
 
     const SceneConst& sc = *D.sc;
     const int S = D.S;
@@ -439,6 +442,8 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
             }
         }
         if (valid) D.info[idx] = info;
+        n_rec += __popcll(__ballot(is_hit(info) && (info & (I_CHILD_T | I_CHILD_I | I_CHILD_R | I_SHADE)) != 0));
+        n_live += __popcll(__ballot(is_hit(info) && (info & I_LIVE)));
 
         // ---- per-tile counters: lane c keeps counter c ---------------------------------------
         unsigned mine = 0;
@@ -451,6 +456,10 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
             D.tile_run[(size_t)(tbase + t) * NCNT + lane] = run;
             run += mine;
         }
+    }
+    if (lane == 0 && n_rec) {
+        atomicAdd(&D.work[3], (unsigned long long)n_rec);
+        atomicAdd(&D.work[4], (unsigned long long)n_live);
     }
     // totals: per workgroup for k_scan, plus every wave's offset inside its workgroup
     __shared__ unsigned s_wtot[WPB][NCNT];

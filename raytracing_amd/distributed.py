@@ -319,8 +319,10 @@ class ShardedRenderer:
 
     def local_stats(self):
         c = self.ctx.counters()
-        return {"rays": int(c["rays"]), "hits": int(c["hits"]), "shaded_hits": int(c["shaded_hits"]),
-                "shaded_samples": int(c["shaded_samples"]), "spheres": self.flat.n_spheres}
+        out = {k: int(v) for k, v in c.items()}
+        out["spheres"] = self.flat.n_spheres
+        out["lights"] = [(l.kind, l.n_points) for l in self.flat.lights]
+        return out
 
 
 def raytrace_sharded(scene, params, comm, backend, rng=None):
@@ -370,7 +372,8 @@ class FrameJob:
     """A benchmark frame on the GPUs of this process group: set-up once, then
     ``step()`` re-renders it with the samples already resident in HBM."""
 
-    def __init__(self, scene_name, width, height, device=0, rank=0, world=1, group=None, private_stream=False):
+    def __init__(self, scene_name, width, height, device=0, rank=0, world=1, group=None, private_stream=False,
+                 precision="mixed"):
         import torch
         from . import _native
         from .Scenes.scenes import build_scene
@@ -390,6 +393,7 @@ class FrameJob:
             if not stream:   # the legacy default stream has handle 0, which rt_create reads as "make your own"
                 raise RuntimeError("run FrameJob under `with torch.cuda.stream(torch.cuda.Stream()):`")
         self.ctx = _native.Context(device, stream)
+        self.precision = precision
         self.r = ShardedRenderer(scene, params, self.comm, self.ctx)
         if world > 1:
             self.r.batch_tensor = torch.zeros(self.r.tree.n_nodes, dtype=torch.int32, device=self.device)
@@ -407,6 +411,7 @@ class FrameJob:
                 self.tile = self.full[r0 * W:r1 * W]
             else:
                 self.tile = torch.empty(((r1 - r0) * W, 3), dtype=torch.float64, device=self.device)
+        self.ctx.set_precision(self.precision)
         r.trace_checked(self.tile.data_ptr() if self.tile is not None else None)
         r.draw_samples()
         self.ctx.profile_enable(True)

@@ -227,3 +227,34 @@ def test_batch_sizes_in_caller_owned_device_memory(golden_dir):
         r.ctx.trace_geometry()
         r.shade()
         assert np.array_equal(r.image().reshape(90, 160, 3), img)
+
+
+# Ray / hit / shadow-ray / random-number counts of the REFERENCE at 1920x1080 (seed 0),
+# recorded when the reference itself was run at that size.
+FULL_HD_REFERENCE_COUNTS = {
+    "example_1": dict(rays=37_336_983, shadow=20_571_993),
+    "example_2": dict(rays=24_405_826, shadow=13_154_208),
+    "example_3": dict(rays=43_182_942, shadow=25_755_003),
+    "example_4": dict(rays=44_323_426, shadow=780_860_790, uniforms=1_561_721_580),
+}
+
+
+@pytest.mark.parametrize("name", EXAMPLES)
+def test_full_hd_counts_equal_the_reference_run(name):
+    """At 1920x1080 the reference is too slow to re-run in a test, but its integer
+    counters were recorded: every nearest-hit decision of 24-44 million rays has to
+    agree for these to match.  (The reference casts one shadow ray per hit and light
+    sample, also for hits whose colour is later multiplied by zero.)"""
+    want = FULL_HD_REFERENCE_COUNTS[name]
+    scene = build_scene(name, 1920, 1080)
+    np.random.seed(0)
+    with Renderer(scene) as r:
+        r.begin_rows(0, 1080)
+        r.trace()
+        n_uniforms = r.draw_samples()
+        cnt = r.counters()
+        samples_per_hit = sum(l.n_points for l in r.flat.lights)
+    assert cnt["rays"] == want["rays"]
+    assert cnt["hits"] * samples_per_hit == want["shadow"]
+    if "uniforms" in want:
+        assert n_uniforms == want["uniforms"]
