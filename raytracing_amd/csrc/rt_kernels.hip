@@ -118,6 +118,8 @@ __device__ __forceinline__ bool is_hit(uint32_t info) { return (info & I_SID_MAS
 // Whether a ray with this info word is counted by counter c.
 __device__ __forceinline__ bool counted(uint32_t info, int c) {
     if (c == C_HIT) return is_hit(info);
+    if (c == C_REC) return is_hit(info) && (info & (I_CHILD_T | I_CHILD_I | I_CHILD_R | I_SHADE)) != 0;
+    if (c == C_LIVE) return is_hit(info) && (info & I_LIVE) != 0;
     const int bit = c < 3 ? 18 + c : (c == C_SHADE ? 21 : I_BEAM_SHIFT + (c - C_BEAM0));
     return (info >> bit) & 1u;
 }
@@ -221,7 +223,6 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
     const int wid = blockIdx.x * WPB + wave;
     const int t_first = wid * q;
     unsigned run = 0;  // lanes 0..NCNT-1: running counters of this wave
-    unsigned n_rec = 0, n_live = 0;   // hit records / (A, path length) pairs this wave stored
 
     const SceneConst& sc = *D.sc;
     const int S = D.S;
@@ -442,8 +443,6 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
             }
         }
         if (valid) D.info[idx] = info;
-        n_rec += __popcll(__ballot(is_hit(info) && (info & (I_CHILD_T | I_CHILD_I | I_CHILD_R | I_SHADE)) != 0));
-        n_live += __popcll(__ballot(is_hit(info) && (info & I_LIVE)));
 
         // ---- per-tile counters: lane c keeps counter c ---------------------------------------
         unsigned mine = 0;
@@ -456,10 +455,6 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
             D.tile_run[(size_t)(tbase + t) * NCNT + lane] = run;
             run += mine;
         }
-    }
-    if (lane == 0 && n_rec) {
-        atomicAdd(&D.work[3], (unsigned long long)n_rec);
-        atomicAdd(&D.work[4], (unsigned long long)n_live);
     }
     // totals: per workgroup for k_scan, plus every wave's offset inside its workgroup
     __shared__ unsigned s_wtot[WPB][NCNT];
@@ -536,11 +531,15 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
             }
         } else if (c == C_HIT) {
             D.node_hits[k] = (int)tot;
-        } else if (c != C_SHADE) {
+        } else if (c >= C_BEAM0 && c < C_BEAM0 + RT_MAX_LIGHTS) {
             D.node_beam[k * RT_MAX_LIGHTS + (c - C_BEAM0)] = (int)tot;
         }
     }
-    if (tid == 0) D.lvl_shade_base[level + 1] = D.lvl_shade_base[level] + (int)s_grand[C_SHADE];
+    if (tid == 0) {
+        D.lvl_shade_base[level + 1] = D.lvl_shade_base[level] + (int)s_grand[C_SHADE];
+        D.work[3] += s_grand[C_REC];     // only this workgroup touches them between k_init and the host
+        D.work[4] += s_grand[C_LIVE];
+    }
     __syncthreads();
 
     // 3. layout of the next level: every node gets whole tiles (block-wide prefix over nodes)

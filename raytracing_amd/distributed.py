@@ -414,7 +414,7 @@ class FrameJob:
         self.ctx.set_precision(self.precision)
         r.trace_checked(self.tile.data_ptr() if self.tile is not None else None)
         r.draw_samples()
-        self.ctx.profile_enable(True)
+        self.ctx.profile_enable(os.environ.get("RT_BENCH_PROFILE", "1") != "0")
         self.step()
         self.synchronize()
         self._stats = r.global_stats()

@@ -213,6 +213,7 @@ def test_batch_sizes_in_caller_owned_device_memory(golden_dir):
     scene = build_scene("example_3", 160, 90)
     with Renderer(scene, precision="f64") as r:
         buf = torch.zeros(r.tree.n_nodes, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()        # the fill ran on torch's stream, the renderer has its own
         r.ctx.set_batch_buffer(buf.data_ptr())
         r.begin_rows(0, 90)
         for level in range(r.tree.n_levels):
@@ -220,6 +221,7 @@ def test_batch_sizes_in_caller_owned_device_memory(golden_dir):
         batch, hits, beam = r.ctx.node_counts()
         r.shade()
         img = r.image().reshape(90, 160, 3)
+        r.ctx.synchronize()
         assert np.array_equal(buf.cpu().numpy(), batch)          # one GPU: global == local
         # shrinking a batch below the limit in the buffer kills that node on the next frame
         assert np.abs(img - g["example_3_image"]).max() <= TOL
