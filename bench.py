@@ -14,6 +14,14 @@ Metric: Mrays/s, rays = rays handed to the nearest-hit search (the
 reference-equivalent count: sum of the batch sizes of all tree nodes whose
 whole-image batch is >= 3), summed over the four frames and all GPUs.
 
+Two timed regions of K steps each, both bracketed by barrier + synchronize:
+1. the metric: the four frames are independent, each runs on its own HIP
+   stream, so their latency-bound deep levels overlap (`value`, `ms_per_step`);
+2. the same steps with the frames one after the other and HIP events around
+   every kernel launch on the kernel's stream: per-kernel durations without
+   overlap, from which `kernel_ms_per_step` and the rooflines are computed
+   (`ms_per_step_frames_sequential` is this region's wall time per step).
+
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every
 frame is split into N contiguous row blocks of equal estimated cost; ranks
 exchange per-node batch sizes after every bounce level (the small-batch rule
@@ -74,8 +82,6 @@ def main():
     ap.add_argument("--scenes", nargs="*", default=SCENES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["mixed", "f64"], default="mixed")
-    ap.add_argument("--overlap-frames", action="store_true",
-                    help="one private stream per frame: frames overlap (higher throughput, per-kernel times inflate)")
     args = ap.parse_args()
 
     import torch
@@ -85,49 +91,58 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local_rank)
     W, H = args.width, args.height
-    # every kernel of every frame goes to this one stream (so do the tile transfers), which
-    # keeps the per-kernel event timings free of overlap
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
 
     # ---- set-up: geometry once, then draw + upload the disk-light samples -------------------
     t_setup = time.perf_counter()
     jobs = []
     for name in args.scenes:
-        job = FrameJob(name, W, H, device=local_rank, rank=rank, world=world, group=group,
-                       private_stream=args.overlap_frames, precision=args.precision)
+        job = FrameJob(name, W, H, device=local_rank, rank=rank, world=world, group=group, precision=args.precision)
         np.random.seed(0)
         job.prepare()            # first geometry pass, row split, samples resident in HBM
         jobs.append(job)
     setup_s = time.perf_counter() - t_setup
 
-    def step():
-        for job in jobs:
-            job.step()           # geometry + shade, asynchronous on the job's stream
-
-    def sync_all():
+    def barrier():
         for job in jobs:
             job.synchronize()
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier(group=group)
 
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+        return float(t.item())
+
+    # ---- timed region 1: the metric.  Frames are independent, every frame has its own stream,
+    # so the latency-bound deep levels of one frame overlap the others.  No per-kernel events.
     for _ in range(args.warmup):
-        step()
-    sync_all()
-    for job in jobs:
-        job.profile(reset=True)
-    torch.cuda.synchronize()
+        for job in jobs:
+            job.step()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        for job in jobs:
+            job.step()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    # ---- timed region 2: the same steps with the frames one after the other and HIP events
+    # around every kernel on its stream, so that per-kernel durations are free of overlap; the
+    # rooflines below come from this region
     for job in jobs:
-        job.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
-        elapsed = float(t.item())
+        job.profile_enable(True)
+        job.profile(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for job in jobs:
+            job.step()
+            job.synchronize()
+    barrier()
+    elapsed_seq = max_over_ranks(time.perf_counter() - t0)
 
     # ---- bookkeeping ----------------------------------------------------------------------
     stats = [job.stats() for job in jobs]            # global (all-rank) counts per frame
@@ -191,7 +206,8 @@ def main():
     out = {
         "metric": "Mrays/s (primary+secondary) at 3840x2160 example scenes",
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True,
+        "ms_per_step": ms_per_step, "ms_per_step_frames_sequential": elapsed_seq / args.steps * 1e3,
+        "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
         "dtype": "f64 geometry + f32 disk-light samples (f64 re-check)" if mixed else "f64", "data": "synthetic",
         "config": {"workload": f"{'+'.join(args.scenes)} at {W}x{H}, depths (3,5), example_4 with 30 disk samples/hit "

@@ -370,10 +370,12 @@ def raytrace(scene, *, params=None, device=None):
 # ----------------------------------------------------------------------------------------------
 class FrameJob:
     """A benchmark frame on the GPUs of this process group: set-up once, then
-    ``step()`` re-renders it with the samples already resident in HBM."""
+    ``step()`` re-renders it with the samples already resident in HBM.  Every job
+    owns a HIP stream (kernels, collectives and tile transfers of the frame are
+    ordered on it), so the steps of different jobs overlap unless the caller
+    synchronises between them."""
 
-    def __init__(self, scene_name, width, height, device=0, rank=0, world=1, group=None, private_stream=False,
-                 precision="mixed"):
+    def __init__(self, scene_name, width, height, device=0, rank=0, world=1, group=None, precision="mixed"):
         import torch
         from . import _native
         from .Scenes.scenes import build_scene
@@ -383,38 +385,31 @@ class FrameJob:
         self.comm = Comm(group, self.device if world > 1 else None)
         scene = build_scene(scene_name, width, height)
         params = RenderParams(width=width, height=height)
-        # torch's current stream by default (kernels of successive frames run one after the
-        # other and tile transfers are ordered after the kernels); a private stream per frame
-        # lets the small launches of different frames overlap on a single GPU
-        if private_stream and world == 1:
-            stream = None
-        else:
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            if not stream:   # the legacy default stream has handle 0, which rt_create reads as "make your own"
-                raise RuntimeError("run FrameJob under `with torch.cuda.stream(torch.cuda.Stream()):`")
-        self.ctx = _native.Context(device, stream)
+        self.stream = torch.cuda.Stream(self.device)
+        self.ctx = _native.Context(device, self.stream.cuda_stream)
         self.precision = precision
         self.r = ShardedRenderer(scene, params, self.comm, self.ctx)
         if world > 1:
-            self.r.batch_tensor = torch.zeros(self.r.tree.n_nodes, dtype=torch.int32, device=self.device)
+            with torch.cuda.stream(self.stream):
+                self.r.batch_tensor = torch.zeros(self.r.tree.n_nodes, dtype=torch.int32, device=self.device)
         self.width, self.height = width, height
         self.full = self.tile = None
 
     def prepare(self):
         torch, r = self.torch, self.r
-        r.choose_rows()
-        r0, r1 = r.my_rows
-        W = self.width
-        if self.comm.world > 1:
-            if self.comm.rank == 0:
-                self.full = torch.empty((self.height * W, 3), dtype=torch.float64, device=self.device)
-                self.tile = self.full[r0 * W:r1 * W]
-            else:
-                self.tile = torch.empty(((r1 - r0) * W, 3), dtype=torch.float64, device=self.device)
-        self.ctx.set_precision(self.precision)
-        r.trace_checked(self.tile.data_ptr() if self.tile is not None else None)
-        r.draw_samples()
-        self.ctx.profile_enable(os.environ.get("RT_BENCH_PROFILE", "1") != "0")
+        with torch.cuda.stream(self.stream):
+            r.choose_rows()
+            r0, r1 = r.my_rows
+            W = self.width
+            if self.comm.world > 1:
+                if self.comm.rank == 0:
+                    self.full = torch.empty((self.height * W, 3), dtype=torch.float64, device=self.device)
+                    self.tile = self.full[r0 * W:r1 * W]
+                else:
+                    self.tile = torch.empty(((r1 - r0) * W, 3), dtype=torch.float64, device=self.device)
+            self.ctx.set_precision(self.precision)
+            r.trace_checked(self.tile.data_ptr() if self.tile is not None else None)
+            r.draw_samples()
         self.step()
         self.synchronize()
         self._stats = r.global_stats()
@@ -422,22 +417,25 @@ class FrameJob:
 
     def step(self):
         r = self.r
-        r.trace()
-        r.shade()
-        if self.comm.world > 1:
-            self.comm.gather_tiles(self.full, self.tile, r.bounds, self.width)
+        with self.torch.cuda.stream(self.stream):
+            r.trace()
+            r.shade()
+            if self.comm.world > 1:
+                self.comm.gather_tiles(self.full, self.tile, r.bounds, self.width)
 
     def synchronize(self):
-        self.ctx.synchronize()
+        self.stream.synchronize()
 
     def image(self):
         """Rank 0: the whole frame as a NumPy array (other ranks: their tile)."""
         if self.comm.world == 1:
             return self.ctx.read_image().reshape(self.height, self.width, 3)
         self.synchronize()
-        self.torch.cuda.synchronize()
         t = self.full if self.comm.rank == 0 else self.tile
         return t.cpu().numpy().reshape(-1, self.width, 3)
+
+    def profile_enable(self, on=True):
+        self.ctx.profile_enable(on)
 
     def profile(self, reset=False):
         return self.ctx.profile(reset)
