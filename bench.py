@@ -72,6 +72,24 @@ def cpu_baseline(seconds_budget=25.0):
                       f"host has {os.cpu_count()} logical CPUs)"}
 
 
+def measured_traffic(kernel, args, world):
+    """HBM bytes per launch of `kernel` from the newest committed PMC measurement of this same
+    workload (profiles/rNN/pmc_traffic.json, made by tools/pmc_traffic.py); None when the
+    workload differs from the measured one."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        with open(path) as f:
+            rec = json.load(f)
+        w = rec["workload"]
+        if (w["scenes"] == list(args.scenes) and w["width"] == args.width and w["height"] == args.height
+                and w["precision"] == args.precision and w["n_gpus"] == world):
+            names = [k for k in rec["kernels"] if k.split("<")[0] == kernel]
+            if names:
+                n = sum(rec["kernels"][k]["launches"] for k in names)
+                return sum(rec["kernels"][k]["total"] * rec["kernels"][k]["launches"] for k in names) / n
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +100,9 @@ def main():
     ap.add_argument("--scenes", nargs="*", default=SCENES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["mixed", "f64"], default="mixed")
+    ap.add_argument("--frames", choices=["overlapped", "sequential"], default="overlapped",
+                    help="sequential: region 1 also runs the frames one after the other (profiler runs, "
+                         "so that kernel durations are free of overlap)")
     args = ap.parse_args()
 
     import torch
@@ -118,14 +139,19 @@ def main():
 
     # ---- timed region 1: the metric.  Frames are independent, every frame has its own stream,
     # so the latency-bound deep levels of one frame overlap the others.  No per-kernel events.
+    serial = args.frames == "sequential"
     for _ in range(args.warmup):
         for job in jobs:
             job.step()
+            if serial:
+                job.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for job in jobs:
             job.step()
+            if serial:
+                job.synchronize()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
@@ -188,7 +214,8 @@ def main():
             return None
         achieved = work / t / (1e9 if unit == "GB/s" else 1e12)
         r = {"kernel": "k_" + kind, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-             "frac": achieved / peak, "traffic": None, "launches_per_step": launches,
+             "frac": achieved / peak, "traffic": measured_traffic("k_" + kind, args, world),
+             "algorithmic_per_launch": work / launches, "launches_per_step": launches,
              "avg_launch_ms": t * 1e3 / launches, "work_per_step": work}
         r.update(extra)
         return r
@@ -213,7 +240,8 @@ def main():
         "config": {"workload": f"{'+'.join(args.scenes)} at {W}x{H}, depths (3,5), example_4 with 30 disk samples/hit "
                                f"(seed 0); one step = all frames, geometry + shading",
                    "rays_per_step": rays, "hits_per_step": hits, "shadow_rays_per_step": shadow_rays,
-                   "rows_split": "contiguous cost-balanced row blocks" if world > 1 else "none"},
+                   "rows_split": "contiguous cost-balanced row blocks" if world > 1 else "none",
+                   "frames": args.frames},
         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
         "setup_s": setup_s,
         "roofline": roofline,

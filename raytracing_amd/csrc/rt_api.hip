@@ -114,6 +114,8 @@ struct RtContext {
     uint32_t spot_mask = 0;
     bool disk_lights = false;
     DevBuf<double> X, Y, packed, staging, image;
+    DevBuf<float> packed32;
+    bool have_packed32 = false;
     int64_t pack_base[RT_MAX_LIGHTS] = {0};
     int64_t pack_E = 0;
     DevBuf<int64_t> sample_off;
@@ -151,7 +153,7 @@ struct RtContext {
         D.spot_mask = spot_mask;
         D.X = explicit_xy ? X.p : nullptr; D.Y = explicit_xy ? Y.p : nullptr;
         D.row0 = row0; D.npix = (int32_t)npix;
-        D.packed = packed.p; D.pack_E = pack_E; D.sample_off = sample_off.p;
+        D.packed = packed.p; D.packed32 = have_packed32 ? packed32.p : nullptr; D.pack_E = pack_E; D.sample_off = sample_off.p;
         for (int l = 0; l < RT_MAX_LIGHTS; ++l) D.pack_base[l] = pack_base[l];
         D.image = user_image ? user_image : image.p;
         return D;
@@ -284,7 +286,7 @@ void rt_destroy(RtContext* ctx) {
     ctx->A.release(); ctx->dist.release(); ctx->cr.release(); ctx->cg.release(); ctx->cb.release();
     ctx->info.release(); ctx->link.release(); ctx->list_ray.release(); ctx->redo_list.release(); ctx->list_node.release(); ctx->lvl_shade_base.release();
     for (auto& b : ctx->list_j) b.release();
-    ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->staging.release();
+    ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->packed32.release(); ctx->staging.release();
     ctx->image.release(); ctx->sample_off.release(); ctx->work.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -522,6 +524,9 @@ int rt_set_sample_layout(RtContext* ctx, const int64_t* offsets, int64_t total) 
         if (ctx->sc_host.lights[l].kind != RT_LIGHT_POINT) slots += (int64_t)ctx->sc_host.lights[l].n_points * entries;
     }
     HIP_TRY(ctx->packed.ensure((size_t)slots * 2));
+    // scenes the float32 sample pass can take also keep the pairs rounded to float
+    ctx->have_packed32 = ctx->S <= SREG;
+    if (ctx->have_packed32) HIP_TRY(ctx->packed32.ensure((size_t)slots * 2));
     HIP_TRY(hipMemcpy(ctx->sample_off.p, offsets, n * sizeof(int64_t), hipMemcpyHostToDevice));
     ctx->pack_E = entries;
     ctx->sample_total = total;
@@ -555,7 +560,7 @@ int rt_shade(RtContext* ctx) {
         return fail(RT_ERR_STATE, "the scene has disk lights: upload their samples before shading");
     const Dev D = ctx->dev();
     const bool lds = ctx->S <= SHADE_LDS_SPHERES;
-    const bool mixed = ctx->precision == RT_PRECISION_MIXED && ctx->sampled_lights && ctx->S <= SREG;
+    const bool mixed = ctx->precision == RT_PRECISION_MIXED && ctx->sampled_lights && ctx->S <= SREG && ctx->have_packed32;
     ctx->begin(RT_K_SURFACE);
     if (lds && mixed) hipLaunchKernelGGL((k_surface<true, true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
     else if (lds) hipLaunchKernelGGL((k_surface<true, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);

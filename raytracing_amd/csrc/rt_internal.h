@@ -108,6 +108,7 @@ struct Dev {
     // disk-light samples, packed per shading-list entry: for light l, sample s of entry e is the
     // pair packed[2 * (pack_base[l] + s * pack_E + e)] = (angle uniform, radius uniform)
     double* packed;
+    float* packed32;            // the same pairs rounded to float (mixed-precision pass), or null
     int64_t pack_base[RT_MAX_LIGHTS];
     int64_t pack_E;             // entries of the shading list when the samples were packed
     const int64_t* sample_off;  // [K][RT_MAX_LIGHTS] offset of each (node, light) block in the caller's stream

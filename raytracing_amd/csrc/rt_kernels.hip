@@ -803,7 +803,7 @@ struct HitSphere {
 // fetched eight at a time so that their loads are in flight together.
 constexpr int SAMPLE_BATCH = 8;
 template <bool LDS>
-__device__ void disk_light_mixed(const Dev& D, const ShadowSphere* s_sh, const RtLight& Lt, const double* pk,
+__device__ void disk_light_mixed(const Dev& D, const ShadowSphere* s_sh, const RtLight& Lt, const float* pk,
                                  int64_t stride, V3 Pb, V3 d, V3 n, V3 kdiff, V3 kspec,
                                  double shin, V3& sumId, V3& sumIs, V3& sumKd, V3& sumKs, unsigned& n_unsure) {
     const int S = D.S;
@@ -836,9 +836,9 @@ __device__ void disk_light_mixed(const Dev& D, const ShadowSphere* s_sh, const R
         float ut[SAMPLE_BATCH], ur[SAMPLE_BATCH];
 #pragma unroll
         for (int k = 0; k < SAMPLE_BATCH; ++k) {
-            const double2 u = *reinterpret_cast<const double2*>(pk + (int64_t)min(s0 + k, N - 1) * stride);
-            ut[k] = (float)u.x;
-            ur[k] = (float)u.y;
+            const float2 u = *reinterpret_cast<const float2*>(pk + (int64_t)min(s0 + k, N - 1) * stride);
+            ut[k] = u.x;
+            ur[k] = u.y;
         }
 #pragma unroll
         for (int k = 0; k < SAMPLE_BATCH; ++k) {
@@ -941,7 +941,7 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int64_t entr
         const int64_t stride = 2 * D.pack_E;
         V3 sumId = {0, 0, 0}, sumIs = {0, 0, 0}, sumKd = {0, 0, 0}, sumKs = {0, 0, 0};
         if constexpr (MIXED) {   // the host launches this variant only when S <= SREG
-            disk_light_mixed<LDS>(D, s_sh, Lt, pk, stride, Pb, d, n, kdiff, kspec, shin, sumId, sumIs, sumKd, sumKs,
+            disk_light_mixed<LDS>(D, s_sh, Lt, D.packed32 + 2 * (D.pack_base[l] + entry), stride, Pb, d, n, kdiff, kspec, shin, sumId, sumIs, sumKd, sumKs,
                                   n_fallback);
         } else {
             for (int s = 0; s < N; ++s) {
@@ -993,13 +993,16 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, const double* chunk, int6
             const int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
             if (off < 0 || off + 2 * N * h <= a || off >= b) continue;
             double* dst = D.packed + 2 * (D.pack_base[l] + e);
+            float* dst32 = D.packed32 ? D.packed32 + 2 * (D.pack_base[l] + e) : nullptr;
             for (int part = 0; part < 2; ++part) {
                 const int64_t first = off + (int64_t)part * N * h + jj;     // stream position of row 0
                 int64_t s0 = first >= a ? 0 : (a - first + h - 1) / h;
                 for (int64_t s = s0; s < N; ++s) {
                     const int64_t pos = first + s * h;
                     if (pos >= b) break;
-                    dst[2 * s * E + part] = chunk[pos - a];
+                    const double u = chunk[pos - a];
+                    dst[2 * s * E + part] = u;
+                    if (dst32) dst32[2 * s * E + part] = (float)u;
                 }
             }
         }
