@@ -102,7 +102,7 @@ struct RtContext {
     HostTree tree;
     int S = 0;
 
-    DevBuf<double> geom, mat;
+    DevBuf<double> geom, mat, fres;
     DevBuf<SceneConst> sc;
     DevBuf<int32_t> node_a, node_b, node_branch, node_child, level_start;
     DevBuf<int32_t> node_n, node_nglobal, node_hits, node_beam, node_tile0, node_ntiles, lvl_ntiles, lvl_tilebase, flags;
@@ -138,7 +138,7 @@ struct RtContext {
 
     Dev dev() const {
         Dev D{};
-        D.geom = geom.p; D.mat = mat.p; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
+        D.geom = geom.p; D.mat = mat.p; D.fres = fres.p; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
         D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
         D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
@@ -204,8 +204,8 @@ int use_device(RtContext* ctx) {
 int launch_level(RtContext* ctx, int level) {
     const Dev D = ctx->dev();
     ctx->begin(RT_K_TRACE);
-    if (ctx->S <= SPH_CHUNK_SMALL) hipLaunchKernelGGL((k_trace<SPH_CHUNK_SMALL>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
-    else hipLaunchKernelGGL((k_trace<SPH_CHUNK_LARGE>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
+    if (ctx->S <= SPH_CHUNK_SMALL) hipLaunchKernelGGL((k_trace<true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
+    else hipLaunchKernelGGL((k_trace<false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
     ctx->end();
     ctx->begin(RT_K_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, D, level);
@@ -276,7 +276,7 @@ void rt_destroy(RtContext* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->collect();
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
-    ctx->geom.release(); ctx->mat.release(); ctx->sc.release();
+    ctx->geom.release(); ctx->mat.release(); ctx->fres.release(); ctx->sc.release();
     ctx->node_a.release(); ctx->node_b.release(); ctx->node_branch.release(); ctx->node_child.release();
     ctx->level_start.release(); ctx->node_n.release(); ctx->node_nglobal.release(); ctx->node_hits.release();
     ctx->node_beam.release(); ctx->node_tile0.release(); ctx->node_ntiles.release(); ctx->lvl_ntiles.release();
@@ -339,10 +339,24 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     const size_t S = scene->n_spheres, K = tree.a.size();
     HIP_TRY(ctx->geom.ensure(S * 4));
     HIP_TRY(ctx->mat.ensure(S * RT_MAT_WIDTH));
+    HIP_TRY(ctx->fres.ensure(S * 4));
     HIP_TRY(ctx->sc.ensure(1));
     if (S) {
         HIP_TRY(hipMemcpy(ctx->geom.p, scene->sphere_geom, S * 4 * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->mat.p, scene->sphere_mat, S * RT_MAT_WIDTH * sizeof(double), hipMemcpyHostToDevice));
+        // per-sphere refraction constants (reference raytrace.py:199-201, :237-239): the same
+        // IEEE divisions the reference does per ray, done once
+        std::vector<double> fres(S * 4);
+        const double air = params->air_refractive_index;
+        for (size_t i = 0; i < S; ++i) {
+            const double ior = scene->sphere_mat[i * RT_MAT_WIDTH + 12];
+            const double q = (air - ior) / (air + ior);
+            fres[i * 4 + 0] = air / ior;
+            fres[i * 4 + 1] = ior / air;
+            fres[i * 4 + 2] = q * q;
+            fres[i * 4 + 3] = 0;
+        }
+        HIP_TRY(hipMemcpy(ctx->fres.p, fres.data(), S * 4 * sizeof(double), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemcpy(ctx->sc.p, &sc, sizeof sc, hipMemcpyHostToDevice));
     HIP_TRY(ctx->node_a.ensure(K)); HIP_TRY(ctx->node_b.ensure(K)); HIP_TRY(ctx->node_branch.ensure(K));

@@ -16,7 +16,7 @@ constexpr int NCNT = RT_NUM_COUNTERS; // per-tile counters: 3 child kinds, hits,
 constexpr int MAX_LEVELS = 32;
 constexpr int MAX_LEVEL_NODES = 1024; // widest level of the static ray tree we accept
 constexpr int MAX_NODES = 65536;
-constexpr int SPH_CHUNK_LARGE = 1024; // spheres staged in LDS per pass of the nearest-hit loop
+constexpr int SPH_CHUNK_LARGE = 512;  // spheres staged in LDS per pass of the nearest-hit loop
 constexpr int SPH_CHUNK_SMALL = 64;   // ... for scenes with few spheres (less LDS, more resident workgroups)
 constexpr int SHADE_LDS_SPHERES = 512;
 
@@ -55,6 +55,7 @@ struct Dev {
     // scene
     const double* geom;  // [S][4] centre, radius
     const double* mat;   // [S][18]
+    const double* fres;  // [S][4] air/ior, ior/air, ((air - ior) / (air + ior))^2, unused
     const SceneConst* sc;
     int32_t S;
     int32_t n_lights;

@@ -45,11 +45,51 @@ __device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ V3 ld3(const double* p) { return {p[0], p[1], p[2]}; }
 __device__ __forceinline__ double clip01(double v) { return fmin(fmax(v, 0.0), 1.0); }
 __device__ __forceinline__ V3 clip01(V3 v) { return {clip01(v.x), clip01(v.y), clip01(v.z)}; }
+// ---- correctly rounded float64 sqrt and division without the range scaling --------------
+// The compiler's expansions of sqrt() and '/' wrap the Newton steps below in scaling code for
+// operands near the ends of the exponent range (v_div_scale / v_div_fmas / v_div_fixup,
+// v_ldexp), most of it quarter-rate instructions.  For operands well inside the range the
+// scaling does nothing, so the bare steps give bit-identical (correctly rounded) results;
+// anything else takes the compiler's path.
+__device__ __forceinline__ bool mid_range(double x) {   // 2^-400 <= |x| < 2^400
+    return (((uint32_t)__double2hiint(x) >> 20) & 0x7ffu) - 623u < 800u;
+}
+__device__ __forceinline__ double xsqrt(double x) {
+    if (__builtin_expect(!(mid_range(x) || x == 0), 0)) return sqrt(x);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    g = fma(fma(-g, g, x), h, g);
+    return x == 0 ? x : g;
+}
+// 1 / b to within the accuracy the final quotient step needs (two Newton steps).
+__device__ __forceinline__ double refined_rcp(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(r, fma(-b, r, 1.0), r);
+    r = fma(r, fma(-b, r, 1.0), r);
+    return r;
+}
+// a / b given r = refined_rcp(b); a and b inside the middle of the exponent range (or a == 0).
+__device__ __forceinline__ double quotient(double a, double b, double r) {
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double xdiv(double a, double b) {
+    if (__builtin_expect(!(mid_range(b) && (mid_range(a) || a == 0)), 0)) return a / b;
+    return quotient(a, b, refined_rcp(b));
+}
 // v / |v| with the norm as sqrt of the left-to-right sum of squares and three
 // divisions, the way numpy.linalg.norm + array division round.
 __device__ __forceinline__ V3 normalize(V3 v) {
-    double len = sqrt(dot(v, v));
-    return {v.x / len, v.y / len, v.z / len};
+    const double len = xsqrt(dot(v, v));
+    const bool fast = mid_range(len) && (mid_range(v.x) || v.x == 0) && (mid_range(v.y) || v.y == 0) &&
+                      (mid_range(v.z) || v.z == 0);
+    if (__builtin_expect(!fast, 0)) return {v.x / len, v.y / len, v.z / len};
+    const double r = refined_rcp(len);
+    return {quotient(v.x, len, r), quotient(v.y, len, r), quotient(v.z, len, r)};
 }
 
 // Number of set bits of a wave ballot below the calling lane.
@@ -142,7 +182,7 @@ __device__ __forceinline__ bool sphere_roots(V3 o, V3 d, double d_o, double cx, 
     const double C = (fx * fx + fy * fy + fz * fz) - r2;
     const double disc = B * B - 4 * C;
     if (!(0 <= disc)) return false;
-    const double half_root = sqrt(disc) / 2;
+    const double half_root = xsqrt(disc) / 2;
     const double mid = -B / 2;
     const double x1 = mid + half_root, x2 = mid - half_root;
     lo = fmin(x1, x2);
@@ -158,9 +198,9 @@ struct Surface {
     V3 N;   // normal facing along the ray
     V3 Pb;  // hit point pulled back by epsilon to the side the ray came from
 };
-__device__ __forceinline__ Surface surface_at(V3 P, const double* g, bool inside, double eps) {
+__device__ __forceinline__ Surface surface_at(V3 P, V3 centre, bool inside, double eps) {
     Surface s;
-    s.n = normalize(P - ld3(g));
+    s.n = normalize(P - centre);
     s.N = inside ? s.n : -s.n;
     s.Pb = P - eps * s.N;
     return s;
@@ -206,57 +246,95 @@ __global__ void k_init(Dev D) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Nearest hit + hit record for one level.  Every wave walks its own run of tiles; the
-// only workgroup-wide steps are staging the spheres in LDS.
-template <int SPH_CHUNK>   // spheres staged in LDS per pass (a small value leaves room for more workgroups)
+// Nearest hit + hit record for one level.  Every wave walks its own run of tiles.  All the
+// small tables a tile needs (the level's nodes, the scene constants and, with few spheres,
+// the sphere constants) are staged in LDS once per workgroup, so that the only vector-memory
+// traffic inside the tile loop is the ray data itself: parent index, parent record, hit record.
+struct NodeRec {
+    int tile_end, tile0, n, bits;   // bits: a | b << 8 | branch << 16 | small-batch flag << 24
+};
+struct SphereRec {   // per-sphere constants of the hit record
+    double mu_out, mu_in, r0, ior, floor_, transp, refl_max, pad;
+};
+
+template <bool SMALL>   // SMALL: at most SPH_CHUNK_SMALL spheres, all constants in LDS
 __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int level) {
-    __shared__ int s_tile_end[MAX_LEVEL_NODES];
+    constexpr int SPH_CHUNK = SMALL ? SPH_CHUNK_SMALL : SPH_CHUNK_LARGE;
+    __shared__ NodeRec s_node[MAX_LEVEL_NODES];
     __shared__ double s_sph[SPH_CHUNK][4];
+    __shared__ SphereRec s_rec[SMALL ? SPH_CHUNK_SMALL : 1];
+    __shared__ SceneConst s_sc;
+    static_assert(sizeof(SceneConst) % 8 == 0, "SceneConst is copied in 8-byte words");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
-    for (int i = tid; i < nn; i += BLOCK) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
-
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
     const int q = (nt + NW - 1) / NW;                  // tiles per wave (same for every wave)
     const int wid = blockIdx.x * WPB + wave;
     const int t_first = wid * q;
-    unsigned run = 0;  // lanes 0..NCNT-1: running counters of this wave
-
-    const SceneConst& sc = *D.sc;
     const int S = D.S;
-    const bool single_chunk = S <= SPH_CHUNK;
-    if (single_chunk && blockIdx.x * WPB * q < nt) {
-        for (int i = tid; i < S; i += BLOCK) {
-            const double* g = D.geom + (size_t)i * 4;
-            s_sph[i][0] = g[0]; s_sph[i][1] = g[1]; s_sph[i][2] = g[2]; s_sph[i][3] = g[3] * g[3];
+    const bool block_has_work = blockIdx.x * WPB * q < nt;
+
+    for (int i = tid; i < (int)(sizeof(SceneConst) / 8); i += BLOCK)
+        reinterpret_cast<double*>(&s_sc)[i] = reinterpret_cast<const double*>(D.sc)[i];
+    if (block_has_work) {
+        const int small_num = D.sc->small_num;
+        for (int i = tid; i < nn; i += BLOCK) {
+            const int k = k0 + i;
+            const int t0 = D.node_tile0[k];
+            NodeRec r;
+            r.tile0 = t0;
+            r.tile_end = t0 + D.node_ntiles[k];
+            r.n = D.node_n[k];
+            r.bits = (D.node_a[k] & 0xff) | ((D.node_b[k] & 0xff) << 8) | ((D.node_branch[k] & 0xff) << 16) |
+                     ((D.node_nglobal[k] < small_num) ? (1 << 24) : 0);   // reference raytrace.py:26-27
+            s_node[i] = r;
+        }
+        if (SMALL) {
+            for (int i = tid; i < S; i += BLOCK) {
+                const double* g = D.geom + (size_t)i * 4;
+                const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
+                const double* f = D.fres + (size_t)i * 4;
+                s_sph[i][0] = g[0]; s_sph[i][1] = g[1]; s_sph[i][2] = g[2]; s_sph[i][3] = g[3] * g[3];
+                s_rec[i] = {f[0], f[1], f[2], m[12], m[10], m[11], m[13], 0.0};
+            }
         }
     }
     __syncthreads();
-
+    const SceneConst& sc = s_sc;
     const double eps = sc.eps, air = sc.air;
+    unsigned run = 0;  // lanes 0..NCNT-1: running counters of this wave
 
     // Per-tile facts (node, batch, depths): all wave-uniform.
     struct Meta {
         bool ok, dead;
-        int t, k, first, cnt, a, b, br;
+        int t, first, cnt, a, b, br;
     };
-    int kk = (t_first < nt) ? find_node(s_tile_end, nn, t_first) : 0;   // node cursor of the look-ahead
+    int kk = 0;   // node cursor of the look-ahead
+    if (t_first < nt) {
+        int lo = 0, hi = nn - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_node[mid].tile_end > t_first) hi = mid; else lo = mid + 1;
+        }
+        kk = lo;
+    }
     auto meta_of = [&](int step) {
         Meta m;
         m.t = t_first + step;
         m.ok = step < q && m.t < nt;
         m.dead = true;
-        m.k = k0; m.first = 0; m.cnt = 0; m.a = 0; m.b = 0; m.br = 0;
+        m.first = 0; m.cnt = 0; m.a = 0; m.b = 0; m.br = 0;
         if (m.ok) {
-            while (s_tile_end[kk] <= m.t) ++kk;
-            m.k = __builtin_amdgcn_readfirstlane(k0 + kk);
-            // scalar loads: they do not queue behind the vector loads of the prefetch pipeline
-            m.first = (m.t - D.node_tile0[m.k]) * TILE;
-            m.cnt = min(TILE, D.node_n[m.k] - m.first);
-            m.dead = D.node_nglobal[m.k] < sc.small_num;   // reference raytrace.py:26-27
-            m.a = D.node_a[m.k]; m.b = D.node_b[m.k]; m.br = D.node_branch[m.k];
+            while (s_node[kk].tile_end <= m.t) ++kk;
+            kk = __builtin_amdgcn_readfirstlane(kk);
+            const NodeRec r = s_node[kk];
+            const int bits = __builtin_amdgcn_readfirstlane(r.bits);
+            m.first = (m.t - __builtin_amdgcn_readfirstlane(r.tile0)) * TILE;
+            m.cnt = min(TILE, __builtin_amdgcn_readfirstlane(r.n) - m.first);
+            m.a = bits & 0xff; m.b = (bits >> 8) & 0xff; m.br = (bits >> 16) & 0xff;
+            m.dead = (bits >> 24) & 1;
         }
         return m;
     };
@@ -278,31 +356,26 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
         }
         return r;
     };
+    auto sphere_rec = [&](int sid) -> SphereRec {
+        if (SMALL) return s_rec[sid];
+        const double* m = D.mat + (size_t)sid * RT_MAT_WIDTH;
+        const double* f = D.fres + (size_t)sid * 4;
+        return {f[0], f[1], f[2], m[12], m[10], m[11], m[13], 0.0};
+    };
+    auto sphere_centre = [&](int sid, double& r2) -> V3 {
+        if (SMALL) { r2 = s_sph[sid][3]; return {s_sph[sid][0], s_sph[sid][1], s_sph[sid][2]}; }
+        const double* g = D.geom + (size_t)sid * 4;
+        r2 = g[3] * g[3];
+        return {g[0], g[1], g[2]};
+    };
 
-    // Software pipeline over this wave's tiles: while tile i is computed, the parent records
-    // of tile i+1 and the parent indices of tile i+2 are already in flight.
-    // With more spheres than one LDS chunk the waves of a workgroup must step together.
-    const int steps = single_chunk ? max(0, min(nt, t_first + q) - t_first) : q;
-    Meta m_cur = meta_of(0);
-    uint32_t p_cur = load_link(m_cur);
-    Meta m_nxt = meta_of(1);
-    uint32_t p_nxt = load_link(m_nxt);
-    Parent par_cur = load_parent(m_cur, p_cur);
-    for (int step = 0; step < steps; ++step) {
-        const Parent par_nxt = load_parent(m_nxt, p_nxt);
-        const Meta m_nx2 = meta_of(step + 2);
-        const uint32_t p_nx2 = load_link(m_nx2);
-
-        const Meta m = m_cur;
-        const Parent par = par_cur;
-        m_cur = m_nxt; par_cur = par_nxt; m_nxt = m_nx2; p_nxt = p_nx2;
-
-        const int t = m.t, k = m.k, first = m.first, a = m.a, b = m.b, br = m.br;
+    // ---- one tile ---------------------------------------------------------------------------
+    auto process = [&](const Meta& m, const Parent& par) {
+        const int t = m.t, first = m.first, a = m.a, b = m.b, br = m.br;
         const bool tile_ok = m.ok;
         const uint32_t idx = (uint32_t)(tbase + t) * TILE + lane;
         const bool valid = lane < m.cnt;
         const bool active = valid && !m.dead;
-        (void)k;
 
         // ---- derive the ray ------------------------------------------------------------------
         V3 o = {0, 0, 0}, d = {1, 0, 0};
@@ -324,15 +397,17 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
                 const int psid = pinfo & I_SID_MASK;
                 const bool pinside = pinfo & I_INSIDE;
                 const V3 pd = par.d;
-                const Surface sf = surface_at(par.P, D.geom + (size_t)psid * 4, pinside, eps);
+                double pr2;
+                const V3 pc = sphere_centre(psid, pr2);
+                const Surface sf = surface_at(par.P, pc, pinside, eps);
                 const double cosi = dot(sf.N, pd);
                 if (br == 0) {
                     // transmitted ray (reference raytrace.py:198-212, :104-107): the same
                     // operations on the same values as in the parent's own pass
-                    const double ior = D.mat[(size_t)psid * RT_MAT_WIDTH + 12];
-                    const double mu = pinside ? ior / air : air / ior;
+                    const double mu = SMALL ? (pinside ? s_rec[psid].mu_in : s_rec[psid].mu_out)
+                                            : D.fres[(size_t)psid * 4 + (pinside ? 1 : 0)];
                     const double kk_ = 1 - mu * mu * (1 - cosi * cosi);
-                    const double sk = sqrt(fmax(kk_, 0.0));
+                    const double sk = xsqrt(fmax(kk_, 0.0));
                     d = sk * sf.N + mu * (pd - cosi * sf.N);
                     o = sf.Pb + (2 * eps) * sf.N;
                     live = pinfo & I_LIVE_TI;
@@ -352,7 +427,8 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
         int sid = -1;
         for (int c0 = 0; c0 < S; c0 += SPH_CHUNK) {
             const int cn = min(SPH_CHUNK, S - c0);
-            if (!single_chunk) {
+            if (!SMALL) {
+                // more spheres than one LDS chunk: the waves of the workgroup step together
                 __syncthreads();
                 for (int i = tid; i < cn; i += BLOCK) {
                     const double* g = D.geom + (size_t)(c0 + i) * 4;
@@ -371,42 +447,41 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
                 }
             }
         }
-        if (!tile_ok) continue;
+        if (!tile_ok) return;
 
         // ---- hit record (reference raytrace.py:53-101) -------------------------------------
         uint32_t info = I_NO_HIT | (live && valid ? I_LIVE : 0u);
         if (active && sid >= 0) {
-            const double* g = D.geom + (size_t)sid * 4;
-            const double* m = D.mat + (size_t)sid * RT_MAT_WIDTH;
+            double r2;
+            const V3 centre = sphere_centre(sid, r2);
+            const SphereRec sr = sphere_rec(sid);
             V3 P = o + best * d;
-            V3 n = normalize(P - ld3(g));
+            V3 n = normalize(P - centre);
             const bool inside = dot(d, n) > 0;
-            const double ior = m[12];
-            const double n1 = inside ? ior : air, n2 = inside ? air : ior;
+            const double n1 = inside ? sr.ior : air, n2 = inside ? air : sr.ior;
             V3 N = inside ? n : -n;
             V3 Pb = P - eps * N;
-            const double mu = n1 / n2;
+            const double mu = inside ? sr.mu_in : sr.mu_out;   // n1 / n2
             const double cosi = dot(N, d);
             const double kq = 1 - mu * mu * (1 - cosi * cosi);
             const bool trans = kq >= 0;
             V3 T = {0, 0, 0};
-            if (trans) T = sqrt(kq) * N + mu * (d - cosi * N);  // reference raytrace.py:207-211
-            double r0 = (n1 - n2) / (n1 + n2);
-            r0 *= r0;
+            if (trans) T = xsqrt(kq) * N + mu * (d - cosi * N);  // reference raytrace.py:207-211
+            const double r0 = sr.r0;   // ((n1 - n2) / (n1 + n2))^2, the same value from either side
             const double cosf = (n2 >= n1) ? cosi : dot(T, N);
             const double om = 1 - cosf;
             const double om2 = om * om;
             double R = r0 + (1 - r0) * (om2 * om2 * om);
             if (!trans) R = 1;
-            const double floor_ = inside ? 0.0 : m[10];
-            const double A = floor_ + (m[13] - floor_) * R;
+            const double floor_ = inside ? 0.0 : sr.floor_;
+            const double A = floor_ + (sr.refl_max - floor_) * R;
 
             double through = 0;
             if (b != 0 && trans && !inside) {
                 // distance to the far side of the entered sphere (reference raytrace.py:117-118)
                 double lo, hi;
                 through = -1;
-                if (sphere_roots(Pb, T, dot(T, Pb), g[0], g[1], g[2], g[3] * g[3], lo, hi))
+                if (sphere_roots(Pb, T, dot(T, Pb), centre.x, centre.y, centre.z, r2, lo, hi))
                     through = hi > 0 ? hi : (lo > 0 ? lo : -1.0);
             }
             info = (uint32_t)sid | (live ? I_LIVE : 0u);
@@ -416,20 +491,19 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
             if (a != 0) info |= I_CHILD_R;
             if (live) {
                 // weights of reference raytrace.py:164-166; a zero weight is an exact zero there too
-                if ((1 - m[11]) * (1 - A) != 0) info |= I_SHADE;
-                if (m[11] * (1 - A) != 0) info |= I_LIVE_TI;
+                if ((1 - sr.transp) * (1 - A) != 0) info |= I_SHADE;
+                if (sr.transp * (1 - A) != 0) info |= I_LIVE_TI;
                 if (A != 0) info |= I_LIVE_R;
             }
             for (int l = 0; l < D.n_lights; ++l) {
+                if (!((D.spot_mask >> l) & 1u)) continue;
+                // reference objects.py:204-213
                 const RtLight& Lt = sc.lights[l];
-                if (Lt.kind == RT_LIGHT_SPOT) {
-                    // reference objects.py:204-213
-                    V3 rel = Pb - ld3(Lt.position);
-                    double x = dot(ld3(Lt.x_hat), rel), y = dot(ld3(Lt.y_hat), rel), z = dot(ld3(Lt.normal), rel);
-                    double rho = sqrt(x * x + y * y);
-                    double edge = Lt.radius + Lt.tan_outer * fabs(z);
-                    if (rho <= edge) info |= 1u << (I_BEAM_SHIFT + l);
-                }
+                V3 rel = Pb - ld3(Lt.position);
+                double x = dot(ld3(Lt.x_hat), rel), y = dot(ld3(Lt.y_hat), rel), z = dot(ld3(Lt.normal), rel);
+                double rho = xsqrt(x * x + y * y);
+                double edge = Lt.radius + Lt.tan_outer * fabs(z);
+                if (rho <= edge) info |= 1u << (I_BEAM_SHIFT + l);
             }
             // the record is read by the children (hit point, direction), by k_surface (the
             // same) and by k_combine (A, path length): store only what somebody will read
@@ -455,7 +529,36 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
             D.tile_run[(size_t)(tbase + t) * NCNT + lane] = run;
             run += mine;
         }
+    };
+
+    // Software pipeline over this wave's tiles, two tiles per iteration with two register
+    // sets (A, B): while a tile is computed, the parent record of the next tile and the parent
+    // index of the tile after it are in flight, and no loaded register is copied (a copy
+    // would force the wave to wait for the load at once).
+    const int steps = SMALL ? max(0, min(nt, t_first + q) - t_first) : q;
+    Meta mA = meta_of(0);
+    uint32_t pA = load_link(mA);
+    Meta mB = meta_of(1);
+    uint32_t pB = load_link(mB);
+    Parent parA = load_parent(mA, pA);
+    for (int step = 0; step < steps; step += 2) {
+        // explicit points where a parent index must have arrived (see below)
+        asm volatile("" : "+v"(pB));
+        const Parent parB = load_parent(mB, pB);
+        const Meta mA2 = meta_of(step + 2);
+        pA = load_link(mA2);
+        process(mA, parA);
+        // the parent index is first needed here: keeps the address arithmetic (and with it the
+        // wait for the index load) from being scheduled ahead of the tile's work
+        asm volatile("" : "+v"(pA));
+        parA = load_parent(mA2, pA);
+        const Meta mB2 = meta_of(step + 3);
+        pB = load_link(mB2);
+        if (SMALL ? (step + 1 < steps) : true) process(mB, parB);
+        mA = mA2;
+        mB = mB2;
     }
+
     // totals: per workgroup for k_scan, plus every wave's offset inside its workgroup
     __shared__ unsigned s_wtot[WPB][NCNT];
     if (lane < NCNT) s_wtot[wave][lane] = run;
@@ -1037,7 +1140,7 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
         const double* m = D.mat + (size_t)sid * RT_MAT_WIDTH;
         V3 P = {D.px[ray], D.py[ray], D.pz[ray]};
         V3 d = {D.dx[ray], D.dy[ray], D.dz[ray]};
-        const Surface sf = surface_at(P, g, info & I_INSIDE, eps);
+        const Surface sf = surface_at(P, ld3(g), info & I_INSIDE, eps);
         unsigned unsure = 0;
         V3 surf = surface_color<LDS, MIXED>(D, s_sh, e, info, sf.Pb, d, sf.n, m, my_samples, unsure);
         my_hits += 1;
@@ -1081,7 +1184,7 @@ __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
         const int sid = info & I_SID_MASK;
         V3 P = {D.px[ray], D.py[ray], D.pz[ray]};
         V3 d = {D.dx[ray], D.dy[ray], D.dz[ray]};
-        const Surface sf = surface_at(P, D.geom + (size_t)sid * 4, info & I_INSIDE, eps);
+        const Surface sf = surface_at(P, ld3(D.geom + (size_t)sid * 4), info & I_INSIDE, eps);
         unsigned a = 0, b = 0;
         V3 surf = surface_color<LDS, false>(D, s_sh, e, info, sf.Pb, d, sf.n, D.mat + (size_t)sid * RT_MAT_WIDTH, a, b);
         D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
