@@ -201,6 +201,20 @@ int use_device(RtContext* ctx) {
     return RT_OK;
 }
 
+// Dynamic LDS of the bookkeeping kernels: the per-node tables of one level.
+size_t level_table_bytes(RtContext* ctx, int level) {
+    static const bool raised = [] {
+        // levels wider than ~680 nodes need more than the default 64 KiB of dynamic LDS
+        const int most = MAX_LEVEL_NODES * LEVEL_TABLE_BYTES;
+        bool ok = hipFuncSetAttribute((const void*)k_link, hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)k_combine<true>, hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)k_combine<false>, hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
+        return ok;
+    }();
+    (void)raised;
+    return (size_t)(ctx->tree.level_start[level + 1] - ctx->tree.level_start[level]) * LEVEL_TABLE_BYTES;
+}
+
 int launch_level(RtContext* ctx, int level) {
     const Dev D = ctx->dev();
     ctx->begin(RT_K_TRACE);
@@ -211,7 +225,7 @@ int launch_level(RtContext* ctx, int level) {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, D, level);
     ctx->end();
     ctx->begin(RT_K_LINK);
-    hipLaunchKernelGGL(k_link, dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
+    hipLaunchKernelGGL(k_link, dim3(NB), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
     ctx->end();
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -583,7 +597,10 @@ int rt_shade(RtContext* ctx) {
     ctx->end();
     for (int level = D.n_levels - 1; level >= 0; --level) {
         ctx->begin(RT_K_COMBINE);
-        hipLaunchKernelGGL(k_combine, dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
+        if (ctx->S <= SPH_CHUNK_SMALL)
+            hipLaunchKernelGGL((k_combine<true>), dim3(NB), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
+        else
+            hipLaunchKernelGGL((k_combine<false>), dim3(NB), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
         ctx->end();
     }
     HIP_TRY(hipGetLastError());

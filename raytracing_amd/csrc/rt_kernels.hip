@@ -692,51 +692,94 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
 // issued together so that their latencies overlap.
 constexpr int UNROLL_TILES = 4;
 
+// Per-node tables of one level in (dynamic) LDS for the bookkeeping kernels: tile layout,
+// first arena slot of each child node and the level-wide running value of every counter
+// at the node's first tile.  LEVEL_TABLE_BYTES per node.
+constexpr int LEVEL_TABLE_BYTES = 16 + 16 + 64;
+struct LevelTables {
+    const NodeRec* node;
+    const uint32_t* child;   // [nn][4]
+    const uint32_t* pre;     // [nn][16]; the shading list is level-wide, its entry is 0
+};
+__device__ __forceinline__ LevelTables stage_level_tables(const Dev& D, int level, int* s_dyn, int tid) {
+    const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
+    NodeRec* node = reinterpret_cast<NodeRec*>(s_dyn);
+    uint32_t* child = reinterpret_cast<uint32_t*>(node + nn);
+    uint32_t* pre = child + 4 * nn;
+    for (int i = tid; i < nn; i += BLOCK) {
+        const int k = k0 + i;
+        const int t0 = D.node_tile0[k];
+        node[i] = {t0 + D.node_ntiles[k], t0, D.node_n[k], 0};
+    }
+    for (int i = tid; i < nn * 4; i += BLOCK) {
+        const int c = i & 3;
+        const int ch = c < 3 ? D.node_child[(k0 + (i >> 2)) * 3 + c] : -1;
+        child[i] = ch >= 0 ? D.node_start[ch] : 0u;
+    }
+    for (int i = tid; i < nn * 16; i += BLOCK) {
+        const int c = i & 15;
+        pre[i] = (c < NCNT && c != C_SHADE) ? D.node_pre[(size_t)(k0 + (i >> 4)) * NCNT + c] : 0u;
+    }
+    return {node, child, pre};
+}
+static_assert(NCNT <= 16, "counter tables in LDS have 16 columns");
+__device__ __forceinline__ int find_node(const NodeRec* node, int nn, int t) {
+    int lo = 0, hi = nn - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (node[mid].tile_end > t) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 // Ordered compaction: every child slot of the next level learns its parent, and the
 // hits that need lighting are appended to the dense shading list.
 __global__ __launch_bounds__(BLOCK) void k_link(Dev D, int level) {
-    __shared__ int s_tile_end[MAX_LEVEL_NODES];
+    extern __shared__ int s_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (D.flags[0]) return;  // arena overflow: child slots do not exist
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
-    for (int i = tid; i < nn; i += BLOCK) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
     const int q = (nt + NW - 1) / NW;
     const int wid = blockIdx.x * WPB + wave;
     const int t_begin = wid * q;
     const int t_end = min(nt, t_begin + q);
+    if (blockIdx.x * WPB * q >= nt) return;   // nothing for this workgroup
+    const LevelTables T = stage_level_tables(D, level, s_dyn, tid);
     const bool has_children = level + 1 < D.n_levels;
     const int shade_base = D.lvl_shade_base[level];
     // counters whose ranks are needed: children, shade items, and what sample addressing uses
     uint32_t want = (has_children ? 7u : 0u) | (1u << C_SHADE);
     if (D.list_j[0]) want |= 1u << C_HIT;
     want |= D.spot_mask << C_BEAM0;
+    // lane c: value of counter c at this wave's first tile (k_trace gave the same tiles to
+    // the wave with this index)
+    unsigned wave_base = 0;
+    if (lane < NCNT)
+        wave_base = D.blk_tot[((size_t)level * NCNT + lane) * NB + blockIdx.x] + D.wave_off[((size_t)level * NCNT + lane) * NW + wid];
     __syncthreads();
-    int kk = (t_begin < t_end) ? find_node(s_tile_end, nn, t_begin) : 0;
-    const NodeLane nl = node_lane(D, lane);
+    int kk = (t_begin < t_end) ? find_node(T.node, nn, t_begin) : 0;
     for (int t0 = t_begin; t0 < t_end; t0 += UNROLL_TILES) {
-        int k[UNROLL_TILES];
+        int kn[UNROLL_TILES];            // node of the tile, relative to the level
         uint32_t info[UNROLL_TILES];
-        int base[UNROLL_TILES];         // lane c: rank offset of counter c
-        uint32_t child_at[UNROLL_TILES]; // lane NL_CHILD0 + c: first slot of child node c
-        // phase A: addresses and loads of all tiles of this iteration
+        unsigned trun[UNROLL_TILES];     // lane c: counter c at the tile's start, relative to the wave's
+        // phase A: the loads of all tiles of this iteration
 #pragma unroll
         for (int u = 0; u < UNROLL_TILES; ++u) {
             const int t = t0 + u;
             info[u] = I_NO_HIT;
-            k[u] = k0;
-            base[u] = 0;
-            child_at[u] = 0;
+            kn[u] = 0;
+            trun[u] = 0;
             if (t < t_end) {
-                while (s_tile_end[kk] <= t) ++kk;
-                k[u] = __builtin_amdgcn_readfirstlane(k0 + kk);
-                const int nv = node_fetch(nl, k[u], lane);
-                if (has_children && lane >= NL_CHILD0 && lane < NL_COUNT && nv >= 0) child_at[u] = D.node_start[nv];
-                base[u] = counter_base(D, level, tbase, q, t, k[u], lane);
-                const int first = (t - LANE(nv, NL_TILE0)) * TILE;
-                const int cnt = min(TILE, LANE(nv, NL_N) - first);
+                while (T.node[kk].tile_end <= t) ++kk;
+                kk = __builtin_amdgcn_readfirstlane(kk);
+                kn[u] = kk;
+                const NodeRec r = T.node[kk];
+                const int first = (t - __builtin_amdgcn_readfirstlane(r.tile0)) * TILE;
+                const int cnt = min(TILE, __builtin_amdgcn_readfirstlane(r.n) - first);
                 if (lane < cnt) info[u] = D.info[(uint32_t)(tbase + t) * TILE + lane];
+                if (lane < NCNT) trun[u] = D.tile_run[(size_t)(tbase + t) * NCNT + lane];
             }
         }
         // phase B: ranks and stores
@@ -745,22 +788,24 @@ __global__ __launch_bounds__(BLOCK) void k_link(Dev D, int level) {
             const int t = t0 + u;
             if (t >= t_end) break;
             const uint32_t idx = (uint32_t)(tbase + t) * TILE + lane;
+            // lane c: rank offset of counter c inside the node (inside the level for the shading list)
+            const int base = (int)(wave_base + trun[u] - T.pre[kn[u] * 16 + (lane & 15)]);
             int rank[NCNT];
 #pragma unroll
             for (int c = 0; c < NCNT; ++c) {
                 rank[c] = 0;
-                if ((want >> c) & 1u) rank[c] = lanes_below(__ballot(counted(info[u], c))) + LANE(base[u], c);
+                if ((want >> c) & 1u) rank[c] = lanes_below(__ballot(counted(info[u], c))) + LANE(base, c);
             }
             if (has_children) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    if ((info[u] >> (18 + c)) & 1u) D.link[LANE(child_at[u], NL_CHILD0 + c) + rank[c]] = idx;
+                    if ((info[u] >> (18 + c)) & 1u) D.link[T.child[kn[u] * 4 + c] + rank[c]] = idx;
                 }
             }
             if (info[u] & I_SHADE) {
                 const int e = shade_base + rank[C_SHADE];
                 D.list_ray[e] = idx;
-                D.list_node[e] = (uint16_t)k[u];
+                D.list_node[e] = (uint16_t)(k0 + kn[u]);
                 if (D.list_j[0]) D.list_j[0][e] = (uint32_t)rank[C_HIT];
 #pragma unroll
                 for (int l = 0; l < RT_MAX_LIGHTS; ++l)
@@ -1194,78 +1239,118 @@ __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
 // ---------------------------------------------------------------------------------------------
 // Bottom-up colour combination for one level (reference raytrace.py:155-170); the
 // deepest level runs first.  A ray's colour replaces its surface colour in place.
+// Two tiles per loop iteration; per iteration the loads come in two rounds (the info words
+// and counters, then everything the info words select), each round issued together.
+constexpr int COMBINE_TILES = 2;
+struct CombineSphere {
+    double tr, kr, kg, kb;   // transparency, -attenuation * absorption colour
+};
+template <bool SMALL>   // SMALL: at most SPH_CHUNK_SMALL spheres, their constants in LDS
 __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
-    __shared__ int s_tile_end[MAX_LEVEL_NODES];
+    extern __shared__ int s_dyn[];
+    __shared__ CombineSphere s_cs[SMALL ? SPH_CHUNK_SMALL : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (D.flags[0]) return;
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
-    for (int i = tid; i < nn; i += BLOCK) s_tile_end[i] = D.node_tile0[k0 + i] + D.node_ntiles[k0 + i];
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
     const int q = (nt + NW - 1) / NW;
     const int wid = blockIdx.x * WPB + wave;
     const int t_begin = wid * q;
     const int t_end = min(nt, t_begin + q);
-    __syncthreads();
-    const SceneConst& sc = *D.sc;
-    const V3 bg = ld3(sc.bg);
+    if (blockIdx.x * WPB * q >= nt) return;   // nothing for this workgroup
+    const LevelTables T = stage_level_tables(D, level, s_dyn, tid);
+    auto sphere_consts = [&](int i) -> CombineSphere {
+        const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
+        return {m[11], -m[14] * m[15], -m[14] * m[16], -m[14] * m[17]};
+    };
+    if (SMALL)
+        for (int i = tid; i < D.S; i += BLOCK) s_cs[i] = sphere_consts(i);
+    const V3 bg = ld3(D.sc->bg);
     const bool has_children = level + 1 < D.n_levels;
+    unsigned wave_base = 0;   // lane c < 3: children of kind c before this wave's first tile
+    if (lane < 3)
+        wave_base = D.blk_tot[((size_t)level * NCNT + lane) * NB + blockIdx.x] + D.wave_off[((size_t)level * NCNT + lane) * NW + wid];
+    __syncthreads();
 
-    int kk = (t_begin < t_end) ? find_node(s_tile_end, nn, t_begin) : 0;
-    const NodeLane nl = node_lane(D, lane);
-    for (int t = t_begin; t < t_end; ++t) {
-        while (s_tile_end[kk] <= t) ++kk;
-        const int k = __builtin_amdgcn_readfirstlane(k0 + kk);
-        const int first = (t - D.node_tile0[k]) * TILE;
-        const int cnt = min(TILE, D.node_n[k] - first);
-        const uint32_t idx = (uint32_t)(tbase + t) * TILE + lane;
-        const uint32_t info = (lane < cnt) ? D.info[idx] : I_NO_HIT;
-
-        uint32_t slot[3] = {0, 0, 0};   // arena index of the ray's child of each kind
-        const bool reads_child = ((info & I_LIVE_TI) && (info & (I_CHILD_T | I_CHILD_I))) ||
-                                 ((info & I_LIVE_R) && (info & I_CHILD_R));
-        if (has_children && __ballot(reads_child) != 0) {
-            const int nv = node_fetch(nl, k, lane);
-            uint32_t child_at = 0;
-            if (lane >= NL_CHILD0 && lane < NL_COUNT && nv >= 0) child_at = D.node_start[nv];
-            const int base = counter_base(D, level, tbase, q, t, k, lane);
+    int kk = (t_begin < t_end) ? find_node(T.node, nn, t_begin) : 0;
+    for (int t0 = t_begin; t0 < t_end; t0 += COMBINE_TILES) {
+        int kn[COMBINE_TILES], first[COMBINE_TILES];
+        uint32_t info[COMBINE_TILES];
+        unsigned trun[COMBINE_TILES];
+        // round 1: info words and the running child counts of the tiles
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                slot[c] = LANE(child_at, NL_CHILD0 + c) + LANE(base, c) + lanes_below(__ballot(((info >> (18 + c)) & 1u) != 0));
-        }
-
-        if (info & I_LIVE) {   // nobody reads the colour of a ray whose weight in the pixel is zero
-            V3 col = bg;
-            if (is_hit(info)) {
-                const int sid = info & I_SID_MASK;
-                const bool inside = info & I_INSIDE;
-                const double* m = D.mat + (size_t)sid * RT_MAT_WIDTH;
-                const double A = D.A[idx];
-                const double tr = m[11];
-                V3 surf = {0, 0, 0}, refr = {0, 0, 0}, refl = {0, 0, 0};
-                if (info & I_SHADE) surf = {D.cr[idx], D.cg[idx], D.cb[idx]};
-                if ((info & I_LIVE_TI) && (info & (I_CHILD_T | I_CHILD_I))) {
-                    const uint32_t sl = (info & I_CHILD_T) ? slot[C_T] : slot[C_I];
-                    refr = {D.cr[sl], D.cg[sl], D.cb[sl]};
-                    if ((info & I_CHILD_T) && !inside) {
-                        // absorption inside the entered sphere (reference raytrace.py:119-120)
-                        const double through = D.dist[idx];
-                        const double att = m[14];
-                        refr.x *= exp(-att * m[15] * through);
-                        refr.y *= exp(-att * m[16] * through);
-                        refr.z *= exp(-att * m[17] * through);
-                    }
-                }
-                if ((info & I_LIVE_R) && (info & I_CHILD_R)) {
-                    const uint32_t sl = slot[C_R];
-                    refl = {D.cr[sl], D.cg[sl], D.cb[sl]};
-                }
-                col = clip01(((1 - tr) * (1 - A)) * surf + (tr * (1 - A)) * refr + A * refl);
+        for (int u = 0; u < COMBINE_TILES; ++u) {
+            const int t = t0 + u;
+            info[u] = I_NO_HIT;
+            kn[u] = 0; first[u] = 0; trun[u] = 0;
+            if (t < t_end) {
+                while (T.node[kk].tile_end <= t) ++kk;
+                kk = __builtin_amdgcn_readfirstlane(kk);
+                kn[u] = kk;
+                const NodeRec r = T.node[kk];
+                first[u] = (t - __builtin_amdgcn_readfirstlane(r.tile0)) * TILE;
+                const int cnt = min(TILE, __builtin_amdgcn_readfirstlane(r.n) - first[u]);
+                if (lane < cnt) info[u] = D.info[(uint32_t)(tbase + t) * TILE + lane];
+                if (has_children && lane < 3) trun[u] = D.tile_run[(size_t)(tbase + t) * NCNT + lane];
             }
-            D.cr[idx] = col.x; D.cg[idx] = col.y; D.cb[idx] = col.z;
-            if (level == 0) {
-                double* out = D.image + (size_t)(first + lane) * 3;
-                out[0] = col.x; out[1] = col.y; out[2] = col.z;
+        }
+        // round 2: what the info words select
+        double A[COMBINE_TILES], through[COMBINE_TILES];
+        V3 surf[COMBINE_TILES], refr[COMBINE_TILES], refl[COMBINE_TILES];
+#pragma unroll
+        for (int u = 0; u < COMBINE_TILES; ++u) {
+            const uint32_t idx = (uint32_t)(tbase + t0 + u) * TILE + lane;
+            const uint32_t in = info[u];
+            A[u] = 0; through[u] = 0;
+            surf[u] = {0, 0, 0}; refr[u] = {0, 0, 0}; refl[u] = {0, 0, 0};
+            const bool want_ti = (in & I_LIVE_TI) && (in & (I_CHILD_T | I_CHILD_I));
+            const bool want_r = (in & I_LIVE_R) && (in & I_CHILD_R);
+            uint32_t slot[3] = {0, 0, 0};   // arena index of the ray's child of each kind
+            if (has_children && __ballot(want_ti || want_r) != 0) {
+                const int base = (int)(wave_base + trun[u] - T.pre[kn[u] * 16 + (lane & 15)]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    slot[c] = T.child[kn[u] * 4 + c] + LANE(base, c) + lanes_below(__ballot(((in >> (18 + c)) & 1u) != 0));
+            }
+            if ((in & I_LIVE) && is_hit(in)) {
+                A[u] = D.A[idx];
+                if (in & I_SHADE) surf[u] = {D.cr[idx], D.cg[idx], D.cb[idx]};
+                if (want_ti) {
+                    const uint32_t sl = (in & I_CHILD_T) ? slot[C_T] : slot[C_I];
+                    refr[u] = {D.cr[sl], D.cg[sl], D.cb[sl]};
+                    if ((in & I_CHILD_T) && !(in & I_INSIDE)) through[u] = D.dist[idx];
+                }
+                if (want_r) {
+                    const uint32_t sl = slot[C_R];
+                    refl[u] = {D.cr[sl], D.cg[sl], D.cb[sl]};
+                }
+            }
+        }
+        // arithmetic and stores
+#pragma unroll
+        for (int u = 0; u < COMBINE_TILES; ++u) {
+            const uint32_t idx = (uint32_t)(tbase + t0 + u) * TILE + lane;
+            const uint32_t in = info[u];
+            if (in & I_LIVE) {   // nobody reads the colour of a ray whose weight in the pixel is zero
+                V3 col = bg;
+                if (is_hit(in)) {
+                    const int sid = in & I_SID_MASK;
+                    const CombineSphere cs = SMALL ? s_cs[sid] : sphere_consts(sid);
+                    V3 rf = refr[u];
+                    if ((in & I_LIVE_TI) && (in & I_CHILD_T) && !(in & I_INSIDE)) {
+                        // absorption inside the entered sphere (reference raytrace.py:119-120)
+                        rf.x *= exp(cs.kr * through[u]);
+                        rf.y *= exp(cs.kg * through[u]);
+                        rf.z *= exp(cs.kb * through[u]);
+                    }
+                    col = clip01(((1 - cs.tr) * (1 - A[u])) * surf[u] + (cs.tr * (1 - A[u])) * rf + A[u] * refl[u]);
+                }
+                D.cr[idx] = col.x; D.cg[idx] = col.y; D.cb[idx] = col.z;
+                if (level == 0) {
+                    double* out = D.image + (size_t)(first[u] + lane) * 3;
+                    out[0] = col.x; out[1] = col.y; out[2] = col.z;
+                }
             }
         }
     }
