@@ -437,11 +437,26 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
                 __syncthreads();
             }
             if (active) {
-                for (int i = 0; i < cn; ++i) {
+                // two spheres per iteration: two independent dependency chains in flight
+                int i = 0;
+                for (; i + 1 < cn; i += 2) {
+                    double lo0, hi0, lo1, hi1;
+                    const bool h0 = sphere_roots(o, d, d_o, s_sph[i][0], s_sph[i][1], s_sph[i][2], s_sph[i][3], lo0, hi0);
+                    const bool h1 = sphere_roots(o, d, d_o, s_sph[i + 1][0], s_sph[i + 1][1], s_sph[i + 1][2], s_sph[i + 1][3], lo1, hi1);
+                    // ties go to the later sphere, as the reference's min_t == t update does
+                    if (h0) {
+                        const double tt = lo0 > 0 ? lo0 : hi0;
+                        if (tt > 0 && tt <= best) { best = tt; sid = c0 + i; }
+                    }
+                    if (h1) {
+                        const double tt = lo1 > 0 ? lo1 : hi1;
+                        if (tt > 0 && tt <= best) { best = tt; sid = c0 + i + 1; }
+                    }
+                }
+                if (i < cn) {
                     double lo, hi;
                     if (sphere_roots(o, d, d_o, s_sph[i][0], s_sph[i][1], s_sph[i][2], s_sph[i][3], lo, hi)) {
-                        double tt = lo > 0 ? lo : hi;
-                        // ties go to the later sphere, as the reference's min_t == t update does
+                        const double tt = lo > 0 ? lo : hi;
                         if (tt > 0 && tt <= best) { best = tt; sid = c0 + i; }
                     }
                 }
@@ -465,24 +480,27 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
             const double cosi = dot(N, d);
             const double kq = 1 - mu * mu * (1 - cosi * cosi);
             const bool trans = kq >= 0;
-            V3 T = {0, 0, 0};
-            if (trans) T = xsqrt(kq) * N + mu * (d - cosi * N);  // reference raytrace.py:207-211
-            const double r0 = sr.r0;   // ((n1 - n2) / (n1 + n2))^2, the same value from either side
-            const double cosf = (n2 >= n1) ? cosi : dot(T, N);
-            const double om = 1 - cosf;
-            const double om2 = om * om;
-            double R = r0 + (1 - r0) * (om2 * om2 * om);
-            if (!trans) R = 1;
-            const double floor_ = inside ? 0.0 : sr.floor_;
-            const double A = floor_ + (sr.refl_max - floor_) * R;
-
-            double through = 0;
-            if (b != 0 && trans && !inside) {
-                // distance to the far side of the entered sphere (reference raytrace.py:117-118)
-                double lo, hi;
-                through = -1;
-                if (sphere_roots(Pb, T, dot(T, Pb), centre.x, centre.y, centre.z, r2, lo, hi))
-                    through = hi > 0 ? hi : (lo > 0 ? lo : -1.0);
+            // Reflected fraction and path length inside the sphere only matter for a ray whose
+            // colour reaches the pixel (the others are traced for the batch and hit counts only).
+            double A = 0, through = 0;
+            if (live) {
+                V3 T = {0, 0, 0};
+                if (trans) T = xsqrt(kq) * N + mu * (d - cosi * N);  // reference raytrace.py:207-211
+                const double r0 = sr.r0;   // ((n1 - n2) / (n1 + n2))^2, the same value from either side
+                const double cosf = (n2 >= n1) ? cosi : dot(T, N);
+                const double om = 1 - cosf;
+                const double om2 = om * om;
+                double R = r0 + (1 - r0) * (om2 * om2 * om);
+                if (!trans) R = 1;
+                const double floor_ = inside ? 0.0 : sr.floor_;
+                A = floor_ + (sr.refl_max - floor_) * R;
+                if (b != 0 && trans && !inside) {
+                    // distance to the far side of the entered sphere (reference raytrace.py:117-118)
+                    double lo, hi;
+                    through = -1;
+                    if (sphere_roots(Pb, T, dot(T, Pb), centre.x, centre.y, centre.z, r2, lo, hi))
+                        through = hi > 0 ? hi : (lo > 0 ? lo : -1.0);
+                }
             }
             info = (uint32_t)sid | (live ? I_LIVE : 0u);
             if (inside) info |= I_INSIDE;
@@ -522,6 +540,7 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
         unsigned mine = 0;
 #pragma unroll
         for (int c = 0; c < NCNT; ++c) {
+            if (c >= C_BEAM0 && c < C_BEAM0 + RT_MAX_LIGHTS && !((D.spot_mask >> (c - C_BEAM0)) & 1u)) continue;
             const unsigned n_c = __popcll(__ballot(counted(info, c)));
             if (lane == c) mine = n_c;
         }
