@@ -232,6 +232,15 @@ int rt_set_output(RtContext *ctx, void *device_rgb);
 
 /* Copy the frame's colours, [n_pixels][3] float64 in pixel order (synchronises). */
 int rt_read_image(RtContext *ctx, double *out_rgb);
+/* The reference's output step (reference main.py:32, matplotlib imsave of the float
+ * image): 8-bit channels, value = (uint8)(v * 255) of the clipped colour, [n_pixels][3].
+ * rt_quantise_rgb8 converts the shaded frame on the device into caller-owned DEVICE
+ * memory (NULL: a buffer of the context) without synchronising - the form a multi-GPU
+ * caller gathers (3 instead of 24 bytes per pixel); rt_read_image_rgb8 converts into the context's buffer and copies it to the
+ * host (synchronises).  Call after rt_shade. */
+int rt_quantise_rgb8(RtContext *ctx, void *device_rgb8);
+int rt_read_image_rgb8(RtContext *ctx, uint8_t *out_rgb8);
+
 /* Device address of the same buffer (valid until the next rt_begin_frame). */
 int rt_image_device_ptr(RtContext *ctx, void **out);
 

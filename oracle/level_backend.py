@@ -212,6 +212,10 @@ class CpuContext:
     def read_image(self):
         return self.image.copy()
 
+    def read_image_rgb8(self):
+        from raytracing_amd.imageio import quantise
+        return quantise(self.image)
+
     def synchronize(self):
         pass
 

@@ -94,6 +94,8 @@ SIGNATURES = {
     "rt_shade": (C.c_int, [_P]),
     "rt_set_output": (C.c_int, [_P, _P]),
     "rt_read_image": (C.c_int, [_P, _F64P]),
+    "rt_quantise_rgb8": (C.c_int, [_P, _P]),
+    "rt_read_image_rgb8": (C.c_int, [_P, C.POINTER(C.c_uint8)]),
     "rt_image_device_ptr": (C.c_int, [_P, C.POINTER(_P)]),
     "rt_synchronize": (C.c_int, [_P]),
     "rt_get_counters": (C.c_int, [_P, C.POINTER(RtCounters)]),
@@ -289,6 +291,15 @@ class Context:
     def read_image(self):
         out = np.empty((self.npix, 3), dtype=np.float64)
         _check(self.lib.rt_read_image(self._h, _ptr(out, C.c_double)))
+        return out
+
+    def quantise_rgb8(self, device_ptr=None):
+        """8-bit image into caller-owned device memory (None: the context's buffer); no synchronisation."""
+        _check(self.lib.rt_quantise_rgb8(self._h, _P(device_ptr) if device_ptr else None))
+
+    def read_image_rgb8(self):
+        out = np.empty((self.npix, 3), dtype=np.uint8)
+        _check(self.lib.rt_read_image_rgb8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
     def image_device_ptr(self):

@@ -121,6 +121,8 @@ struct RtContext {
     DevBuf<int64_t> sample_off;
     DevBuf<unsigned long long> work;
     double* user_image = nullptr;
+    DevBuf<uint8_t> image8;
+    uint8_t* user_image8 = nullptr;
     int32_t* user_batches = nullptr;
 
     int64_t npix = 0;
@@ -301,7 +303,7 @@ void rt_destroy(RtContext* ctx) {
     ctx->info.release(); ctx->link.release(); ctx->list_ray.release(); ctx->redo_list.release(); ctx->list_node.release(); ctx->lvl_shade_base.release();
     for (auto& b : ctx->list_j) b.release();
     ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->packed32.release(); ctx->staging.release();
-    ctx->image.release(); ctx->sample_off.release(); ctx->work.release();
+    ctx->image.release(); ctx->image8.release(); ctx->sample_off.release(); ctx->work.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -447,6 +449,7 @@ int rt_begin_frame(RtContext* ctx, int32_t row0, int32_t n_rows, const double* X
         HIP_TRY(hipMemcpy(ctx->Y.p, Y, npix * sizeof(double), hipMemcpyHostToDevice));
     }
     ctx->user_image = nullptr;
+    ctx->user_image8 = nullptr;
     ctx->npix = npix;
     ctx->row0 = X ? 0 : row0;
     ctx->arena_rays = arena_rays;
@@ -642,6 +645,34 @@ int rt_read_image(RtContext* ctx, double* out_rgb) {
     int32_t flag = 0;
     HIP_TRY(hipMemcpyAsync(out_rgb, ctx->user_image ? ctx->user_image : ctx->image.p, (size_t)ctx->npix * 3 * sizeof(double),
                            hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (flag) return fail(RT_ERR_OVERFLOW, "ray arena of %lld rays is too small for this frame", (long long)ctx->arena_rays);
+    return RT_OK;
+}
+
+int rt_quantise_rgb8(RtContext* ctx, void* device_rgb8) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->shaded) return fail(RT_ERR_STATE, "rt_shade has not been called for this frame");
+    const int64_t n = (int64_t)ctx->npix * 3;
+    if (!device_rgb8) {
+        HIP_TRY(ctx->image8.ensure((size_t)n));
+        device_rgb8 = ctx->image8.p;
+    }
+    ctx->user_image8 = (uint8_t*)device_rgb8;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + BLOCK - 1) / BLOCK, 8 * NB));
+    hipLaunchKernelGGL(k_quantise, dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream,
+                       ctx->user_image ? ctx->user_image : ctx->image.p, ctx->user_image8, n);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_read_image_rgb8(RtContext* ctx, uint8_t* out_rgb8) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!out_rgb8) return fail(RT_ERR_INVALID, "out_rgb8 is null");
+    if (int rc = rt_quantise_rgb8(ctx, nullptr)) return rc;
+    int32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(out_rgb8, ctx->user_image8, (size_t)ctx->npix * 3, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (flag) return fail(RT_ERR_OVERFLOW, "ray arena of %lld rays is too small for this frame", (long long)ctx->arena_rays);

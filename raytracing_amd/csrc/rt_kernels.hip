@@ -1375,4 +1375,12 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 8-bit image as the reference's output step stores it (reference main.py:32, plt.imsave
+// of a float RGB array): channel = (uint8)(v * 255) for v already clipped to [0, 1].
+__global__ __launch_bounds__(BLOCK) void k_quantise(const double* __restrict__ rgb, uint8_t* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+        out[i] = (uint8_t)(int)(fmin(fmax(rgb[i], 0.0), 1.0) * 255.0);
+}
+
 }  // namespace rt

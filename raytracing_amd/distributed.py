@@ -325,12 +325,18 @@ class ShardedRenderer:
         return out
 
 
-def raytrace_sharded(scene, params, comm, backend, rng=None):
+def raytrace_sharded(scene, params, comm, backend, rng=None, output="f64"):
     """Render one frame split over the ranks of ``comm``; returns the whole
     ``(height, width, 3)`` image on rank 0 and ``None`` on the other ranks.
     Every rank must call it with the same scene and, for scenes with disk lights,
-    with identically seeded random streams."""
+    with identically seeded random streams.
+
+    ``output="rgb8"`` gathers the tiles as the 8-bit image of the reference's output
+    step (reference main.py:32): each rank quantises its own rows, 3 instead of 24
+    bytes per pixel cross the links."""
     import torch
+    if output not in ("f64", "rgb8"):
+        raise ValueError("output must be 'f64' or 'rgb8'")
     r = ShardedRenderer(scene, params, comm, backend)
     r.choose_rows()
     r.trace_checked()
@@ -338,21 +344,23 @@ def raytrace_sharded(scene, params, comm, backend, rng=None):
     r.shade()
     W, H = r.params.width, r.params.height
     r0, r1 = r.my_rows
-    tile = torch.from_numpy(np.ascontiguousarray(backend.read_image()[:(r1 - r0) * W]))
+    local = backend.read_image_rgb8() if output == "rgb8" else backend.read_image()
+    tile = torch.from_numpy(np.ascontiguousarray(local[:(r1 - r0) * W]))
     if comm.device is not None:
         tile = tile.to(comm.device)
     full = None
     if comm.rank == 0:
-        full = torch.empty((H * W, 3), dtype=torch.float64, device=tile.device)
+        full = torch.empty((H * W, 3), dtype=tile.dtype, device=tile.device)
         full[r0 * W:r1 * W] = tile
     comm.gather_tiles(full, tile, r.bounds, W)
     comm.barrier()
     return full.cpu().numpy().reshape(H, W, 3) if comm.rank == 0 else None
 
 
-def raytrace(scene, *, params=None, device=None):
+def raytrace(scene, *, params=None, device=None, output="f64"):
     """``raytrace(scene)`` for a process group started by ``torch.distributed.run``
-    (one rank per GPU): rank 0 returns the image, the others ``None``."""
+    (one rank per GPU): rank 0 returns the image, the others ``None``.
+    ``output="rgb8"``: the 8-bit image, see :func:`raytrace_sharded`."""
     import torch
     from . import _native
     rank, world, group = init_group(None)
@@ -362,7 +370,7 @@ def raytrace(scene, *, params=None, device=None):
     comm = Comm(group, torch.device("cuda", device) if world > 1 else None)
     ctx = _native.Context(device, torch.cuda.current_stream().cuda_stream)
     try:
-        return raytrace_sharded(scene, params, comm, ctx)
+        return raytrace_sharded(scene, params, comm, ctx, output=output)
     finally:
         ctx.close()
 

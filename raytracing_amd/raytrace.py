@@ -108,6 +108,10 @@ class Renderer:
     def image(self):
         return self.ctx.read_image()
 
+    def image_rgb8(self):
+        """The frame as ``plt.imsave`` would store it: ``(n, 3)`` uint8, quantised on the GPU."""
+        return self.ctx.read_image_rgb8()
+
     def render_pixels(self):
         """All phases for the pixels chosen with begin_rows / begin_pixels."""
         self.trace()
@@ -138,6 +142,19 @@ def raytrace(scene, *, params=None, device=0, precision="mixed"):
         r.begin_rows(0, r.params.height)
         img = r.render_pixels()
         return img.reshape(r.params.height, r.params.width, 3)
+
+
+def raytrace_rgb8(scene, *, params=None, device=0, precision="mixed"):
+    """``raytrace(scene)`` followed by the quantisation of the reference's output step
+    (reference main.py:32): ``(height, width, 3)`` uint8, exactly the bytes
+    ``plt.imsave`` writes for the float image.  The conversion runs on the GPU, so only
+    3 bytes per pixel cross PCIe."""
+    with Renderer(scene, params, device, precision=precision) as r:
+        r.begin_rows(0, r.params.height)
+        r.trace()
+        r.draw_samples()
+        r.shade()
+        return r.image_rgb8().reshape(r.params.height, r.params.width, 3)
 
 
 def get_pixel_color(X, Y, scene, *, params=None, device=0, precision="mixed"):

@@ -17,7 +17,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(REPO, "include", "raytracing_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rt_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

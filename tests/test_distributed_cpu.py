@@ -135,3 +135,29 @@ def test_two_ranks_spotlight_in_beam_ranks(tmp_path):
     res = _run_two_ranks(tmp_path, "spot:quadratic", 96, 54, seed=5)
     assert np.abs(res["image"] - want).max() <= 1e-12
     assert int(res["uniforms"]) == stats.uniforms_drawn
+
+
+def _worker_rgb8(rank, world, port, name, w, h, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        np.random.seed(0)
+        img = raytrace_sharded(build_scene(name, w, h), None, Comm(dist.group.WORLD), CpuContext(), output="rgb8")
+        if rank == 0:
+            np.save(out_path, img)
+        else:
+            assert img is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gather_8bit_tiles(tmp_path):
+    """The tiles travel as the 8-bit image of the reference's output step."""
+    from raytracing_amd.imageio import quantise
+    g = np.load(os.path.join(GOLDEN, "images_160x90.npz"))
+    out = str(tmp_path / "rgb8.npy")
+    mp.spawn(_worker_rgb8, args=(2, _free_port(), "example_2", 160, 90, out), nprocs=2, join=True)
+    img = np.load(out)
+    assert img.dtype == np.uint8 and img.shape == (90, 160, 3)
+    assert (img == quantise(g["example_2_image"])).all()

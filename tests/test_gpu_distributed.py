@@ -65,3 +65,32 @@ def test_two_ranks_on_one_gpu(tmp_path, name, tol):
     r = g[name + "_rays"]
     assert int(res["rays"]) == int(r[r >= 3].sum())
     assert int(res["hits"]) == int(g[name + "_hits"].sum())
+
+
+def _worker_rgb8(rank, world, port, name, w, h, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracing_amd import _native
+        from raytracing_amd.distributed import Comm, raytrace_sharded
+        from raytracing_amd.Scenes.scenes import build_scene
+        ctx = _native.Context(0)
+        np.random.seed(0)
+        img = raytrace_sharded(build_scene(name, w, h), None, Comm(dist.group.WORLD), ctx, output="rgb8")
+        if rank == 0:
+            np.save(out_path, img)
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gather_8bit_tiles(tmp_path):
+    """Each rank quantises its rows on the GPU; rank 0 assembles the 8-bit frame."""
+    from raytracing_amd.imageio import quantise
+    g = np.load(os.path.join(GOLDEN, "images_160x90.npz"))
+    out = str(tmp_path / "rgb8.npy")
+    mp.spawn(_worker_rgb8, args=(2, _free_port(), "example_1", 160, 90, out), nprocs=2, join=True)
+    img = np.load(out)
+    assert img.dtype == np.uint8 and img.shape == (90, 160, 3)
+    assert (img == quantise(g["example_1_image"])).all()

@@ -260,3 +260,45 @@ def test_full_hd_counts_equal_the_reference_run(name):
     assert cnt["hits"] * samples_per_hit == want["shadow"]
     if "uniforms" in want:
         assert n_uniforms == want["uniforms"]
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's output step: 8-bit images, quantised on the GPU, against what the reference
+# wrote through plt.imsave (goldens made by tests/golden/make_golden.py, generator "rgb8").
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["example_1", "example_2", "example_3"])
+def test_rgb8_equals_reference_output(golden_dir, name):
+    from raytracing_amd.raytrace import raytrace_rgb8
+    gold = _load(golden_dir, "rgb8.npz")[name]
+    h, w, _ = gold.shape
+    got = raytrace_rgb8(build_scene(name, w, h))
+    assert got.dtype == np.uint8 and got.shape == gold.shape
+    assert (got == gold).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,max_levels_off", [("f64", 0.0), ("mixed", 5e-3)])
+def test_rgb8_disk_light_scene(golden_dir, precision, max_levels_off):
+    """example_4 at the reference's default 500x500, seed 0.  Float64 samples: the same bytes;
+    float32 samples (colours within 2e-5): a channel may land on the other side of a
+    quantisation step, never further than one level."""
+    from raytracing_amd.raytrace import raytrace_rgb8
+    gold = _load(golden_dir, "rgb8.npz")["example_4"].astype(int)
+    np.random.seed(0)
+    got = raytrace_rgb8(build_scene("example_4", 500, 500), precision=precision).astype(int)
+    diff = np.abs(got - gold)
+    assert diff.max() <= (1 if max_levels_off else 0)
+    assert (diff > 0).mean() <= max_levels_off
+
+
+@pytest.mark.gpu
+def test_main_writes_png(tmp_path):
+    from raytracing_amd import main as rt_main
+    from raytracing_amd.imageio import decode_png
+    from raytracing_amd.raytrace import raytrace
+    out = tmp_path / "result.png"
+    rt_main.main(["example_2", "--width", "96", "--height", "54", "--out", str(out)])
+    px = decode_png(out.read_bytes())
+    assert px.shape == (54, 96, 4) and (px[..., 3] == 255).all()
+    img = raytrace(build_scene("example_2", 96, 54))
+    assert (px[..., :3] == (img * 255).astype(np.uint8)).all()
