@@ -209,6 +209,16 @@ int rt_get_node_counts(RtContext *ctx, int64_t *batch, int64_t *hits, int64_t *b
 int rt_set_sample_layout(RtContext *ctx, const int64_t *offsets /* [n_nodes][RT_MAX_LIGHTS] */, int64_t total);
 int rt_upload_samples(RtContext *ctx, int64_t dst_offset, const double *u, int64_t n);
 
+/* The same samples made on the device instead of drawn on the host and uploaded: the
+ * whole stream of rt_set_sample_layout's `total` values is generated from a NumPy legacy
+ * MT19937 state (numpy.random.get_state(): key[624], pos) exactly as
+ * numpy.random.random(total) would produce it (reference objects.py:132-133 consumes that
+ * stream), and key_out / pos_out receive the state those draws leave behind (for
+ * numpy.random.set_state), so the caller's stream continues as in the reference.
+ * Single-context frames only: the layout must be the whole image's. */
+int rt_generate_samples(RtContext *ctx, const uint32_t *key /* [624] */, int32_t pos,
+                        uint32_t *key_out /* [624] */, int32_t *pos_out);
+
 /* Arithmetic of the disk-light sample loop in rt_shade.
  * RT_PRECISION_F64: every sample in float64, the reference's operations.
  * RT_PRECISION_MIXED (default): samples in float32 with a rigorous error bound on

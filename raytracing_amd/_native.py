@@ -90,6 +90,7 @@ SIGNATURES = {
     "rt_get_node_counts": (C.c_int, [_P, _I64P, _I64P, _I64P]),
     "rt_set_sample_layout": (C.c_int, [_P, _I64P, C.c_int64]),
     "rt_upload_samples": (C.c_int, [_P, C.c_int64, _F64P, C.c_int64]),
+    "rt_generate_samples": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "rt_set_precision": (C.c_int, [_P, C.c_int32]),
     "rt_shade": (C.c_int, [_P]),
     "rt_set_output": (C.c_int, [_P, _P]),
@@ -276,6 +277,18 @@ class Context:
     def upload_samples(self, dst_offset, u):
         u = _f64(u).reshape(-1)
         _check(self.lib.rt_upload_samples(self._h, int(dst_offset), _ptr(u, C.c_double), u.size))
+
+    def generate_samples(self, key, pos):
+        """Generate the whole sample stream on the device from a legacy MT19937 state
+        (``numpy.random.get_state()[1:3]``); returns the state after the draws."""
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        if key.shape != (624,):
+            raise ValueError("MT19937 key must have 624 words")
+        key_out = np.empty(624, dtype=np.uint32)
+        pos_out = C.c_int32(0)
+        _check(self.lib.rt_generate_samples(self._h, key.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos),
+                                            key_out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos_out)))
+        return key_out, int(pos_out.value)
 
     def set_precision(self, mode):
         """"f64" or "mixed" (see rt_set_precision in the header)."""

@@ -122,6 +122,8 @@ struct RtContext {
     DevBuf<unsigned long long> work;
     double* user_image = nullptr;
     DevBuf<uint8_t> image8;
+    DevBuf<uint32_t> mt_ring, mt_raw;
+    DevBuf<long long> mt_end;
     uint8_t* user_image8 = nullptr;
     int32_t* user_batches = nullptr;
 
@@ -303,7 +305,7 @@ void rt_destroy(RtContext* ctx) {
     ctx->info.release(); ctx->link.release(); ctx->list_ray.release(); ctx->redo_list.release(); ctx->list_node.release(); ctx->lvl_shade_base.release();
     for (auto& b : ctx->list_j) b.release();
     ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->packed32.release(); ctx->staging.release();
-    ctx->image.release(); ctx->image8.release(); ctx->sample_off.release(); ctx->work.release();
+    ctx->image.release(); ctx->image8.release(); ctx->mt_ring.release(); ctx->mt_raw.release(); ctx->mt_end.release(); ctx->sample_off.release(); ctx->work.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -577,10 +579,57 @@ int rt_upload_samples(RtContext* ctx, int64_t dst_offset, const double* u, int64
     HIP_TRY(hipMemcpyAsync(ctx->staging.p, u, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (ctx->pack_E > 0) {
         const int64_t blocks = std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB);
-        hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(), ctx->staging.p, dst_offset, n);
+        hipLaunchKernelGGL((k_pack<UploadedStream>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(),
+                           UploadedStream{ctx->staging.p}, dst_offset, n);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller
+    return RT_OK;
+}
+
+int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32_t* key_out, int32_t* pos_out) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->layout_set) return fail(RT_ERR_STATE, "rt_set_sample_layout has not been called");
+    if (!key || !key_out || !pos_out) return fail(RT_ERR_INVALID, "null argument");
+    if (pos < 0 || pos > MT_N) return fail(RT_ERR_INVALID, "MT19937 position %d out of range", pos);
+    const long long total = ctx->sample_total;          // doubles; two 32-bit outputs each
+    if (total == 0) {
+        memcpy(key_out, key, MT_N * sizeof(uint32_t));
+        *pos_out = pos;
+        return RT_OK;
+    }
+    // x[0..624) is the caller's key block, the first output consumed is x[pos]
+    std::vector<uint32_t> ring(MT_RING, 0u);
+    memcpy(ring.data(), key, MT_N * sizeof(uint32_t));
+    long long gen_end = MT_N;
+    constexpr long long CHUNK = 1ll << 25;              // doubles per piece (256 MiB of raw words)
+    HIP_TRY(ctx->mt_ring.ensure(MT_RING));
+    HIP_TRY(ctx->mt_end.ensure(1));
+    HIP_TRY(ctx->mt_raw.ensure((size_t)std::min(CHUNK, total) * 2));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(ctx->mt_ring.p, ring.data(), MT_RING * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->mt_end.p, &gen_end, sizeof gen_end, hipMemcpyHostToDevice));
+    const Dev D = ctx->dev();
+    const int64_t pack_blocks = std::max<int64_t>(1, std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB));
+    for (long long a = 0; a < total; a += CHUNK) {
+        const long long n = std::min(CHUNK, total - a);
+        hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, ctx->mt_raw.p,
+                           (long long)pos + 2 * a, 2 * n, 0ll);
+        if (ctx->pack_E > 0)
+            hipLaunchKernelGGL((k_pack<GeneratedStream>), dim3((unsigned)pack_blocks), dim3(BLOCK), 0, ctx->stream, D,
+                               GeneratedStream{ctx->mt_raw.p}, (int64_t)a, (int64_t)n);
+    }
+    // The state NumPy would be left in: the key block that holds the last word consumed and
+    // the position after it (a position of 624 means "regenerate at the next draw").
+    const long long next = (long long)pos + 2 * total;     // first word not consumed
+    const long long block = (next - 1) / MT_N;
+    hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, ctx->mt_raw.p,
+                       0ll, 0ll, (block + 1) * MT_N);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ring.data(), ctx->mt_ring.p, MT_RING * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < MT_N; ++i) key_out[i] = ring[(block * MT_N + i) & (MT_RING - 1)];
+    *pos_out = (int32_t)(next - block * MT_N);
     return RT_OK;
 }
 

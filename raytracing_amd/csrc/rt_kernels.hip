@@ -1137,7 +1137,32 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int64_t entr
 // hits on the shading list ever read their columns, so every uploaded piece of the
 // stream, chunk[0..n) = stream[a..a+n), is scattered straight into the packed layout
 // (entry-major within a sample, so k_surface reads it fully coalesced).
-__global__ __launch_bounds__(BLOCK) void k_pack(Dev D, const double* chunk, int64_t a, int64_t n) {
+// Source of stream values for k_pack: doubles the caller uploaded ...
+struct UploadedStream {
+    const double* chunk;   // chunk[i] = stream[a + i]
+    __device__ __forceinline__ double operator()(int64_t i) const { return chunk[i]; }
+};
+// ... or raw MT19937 state words made on the device: value i of the piece is built from words
+// 2i and 2i+1 exactly as NumPy's legacy random_sample does (53-bit resolution:
+// (a >> 5) * 2^26 + (b >> 6), over 2^53, a and b tempered outputs).
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+struct GeneratedStream {
+    const uint32_t* raw;   // raw[2 i], raw[2 i + 1]: untempered words of stream[a + i]
+    __device__ __forceinline__ double operator()(int64_t i) const {
+        const uint2 w = reinterpret_cast<const uint2*>(raw)[i];
+        const uint32_t hi = mt_temper(w.x) >> 5, lo = mt_temper(w.y) >> 6;
+        return ((double)hi * 67108864.0 + (double)lo) / 9007199254740992.0;
+    }
+};
+
+template <typename Stream>
+__global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, int64_t n) {
     const SceneConst& sc = *D.sc;
     const int64_t b = a + n;
     const int64_t E = D.pack_E;
@@ -1167,13 +1192,70 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, const double* chunk, int6
                 for (int64_t s = s0; s < N; ++s) {
                     const int64_t pos = first + s * h;
                     if (pos >= b) break;
-                    const double u = chunk[pos - a];
+                    const double u = chunk(pos - a);
                     dst[2 * s * E + part] = u;
                     if (dst32) dst32[2 * s * E + part] = (float)u;
                 }
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MT19937 state sequence on the device (the generator behind NumPy's legacy global stream,
+// numpy.random.random / RandomState).  x[n + 624] = x[n + 397] ^ twist(x[n], x[n + 1]).
+// One workgroup: lane j of 227 computes x[g + j], g advancing by 227 per step - its own
+// previous result is x[g + j - 227] = the x[n + 397] term, the twist operands are 624 back in
+// an LDS ring and were written at least two steps earlier, so one barrier per two steps is
+// enough (the ring of 2048 keeps writes clear of anything still being read).
+//   ring[2048]  x[n] at slot n & 2047 for the last 2048 indices below *gen_end (in and out)
+//   raw[i]      receives x[raw_first + i] for 0 <= i < raw_n (untempered)
+//   generates until *gen_end >= max(raw_first + raw_n, gen_until)
+constexpr int MT_N = 624, MT_M = 397, MT_STEP = MT_N - MT_M, MT_RING = 2048;
+__device__ __forceinline__ uint32_t mt_twist(uint32_t lo, uint32_t hi) {
+    const uint32_t y = (lo & 0x80000000u) | (hi & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__global__ __launch_bounds__(256) void k_mt_generate(uint32_t* ring_g, long long* gen_end_g, uint32_t* raw,
+                                                     long long raw_first, long long raw_n, long long gen_until) {
+    __shared__ uint32_t ring[MT_RING];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MT_RING; i += 256) ring[i] = ring_g[i];
+    const long long g0 = *gen_end_g;
+    const long long raw_end = raw_first + raw_n;
+    const long long target = raw_end > gen_until ? raw_end : gen_until;
+    __syncthreads();
+    // words of the window that exist already
+    for (long long n = raw_first + tid; n < raw_end && n < g0; n += 256) raw[n - raw_first] = ring[n & (MT_RING - 1)];
+    // two steps per iteration (all four twist operands were written before the previous
+    // barrier); positions as 32-bit offsets from g0
+    const long long todo = target > g0 ? target - g0 : 0;
+    const int iters = (int)((todo + 2 * MT_STEP - 1) / (2 * MT_STEP));
+    const bool lane_on = tid < MT_STEP;
+    const int base = (int)(g0 & (MT_RING - 1));
+    uint32_t prev = lane_on ? ring[(base + tid - MT_STEP) & (MT_RING - 1)] : 0u;
+    // raw index of this lane's word in step 0, relative to the window (may be negative)
+    long long rel = g0 + tid - raw_first;
+    int slot = (base + tid) & (MT_RING - 1);
+    for (int it = 0; it < iters; ++it) {
+        if (lane_on) {
+            const int s0 = slot, s1 = (slot + MT_STEP) & (MT_RING - 1);
+            const uint32_t lo0 = ring[(s0 - MT_N) & (MT_RING - 1)], hi0 = ring[(s0 - MT_N + 1) & (MT_RING - 1)];
+            const uint32_t lo1 = ring[(s1 - MT_N) & (MT_RING - 1)], hi1 = ring[(s1 - MT_N + 1) & (MT_RING - 1)];
+            const uint32_t x0 = prev ^ mt_twist(lo0, hi0);
+            const uint32_t x1 = x0 ^ mt_twist(lo1, hi1);
+            ring[s0] = x0;
+            ring[s1] = x1;
+            if (rel >= 0 && rel < raw_n) raw[rel] = x0;
+            if (rel + MT_STEP >= 0 && rel + MT_STEP < raw_n) raw[rel + MT_STEP] = x1;
+            prev = x1;
+        }
+        slot = (slot + 2 * MT_STEP) & (MT_RING - 1);
+        rel += 2 * MT_STEP;
+        __syncthreads();
+    }
+    for (int i = tid; i < MT_RING; i += 256) ring_g[i] = ring[i];
+    if (tid == 0) *gen_end_g = g0 + (long long)iters * 2 * MT_STEP;
 }
 
 // ---------------------------------------------------------------------------------------------

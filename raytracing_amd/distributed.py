@@ -31,6 +31,7 @@ import numpy as np
 
 from .constants import RenderParams
 from .flatten import FlatScene, flatten_scene, LIGHT_SPOT
+from .raytrace import legacy_mt19937_state
 from .tree import build_tree, sample_offsets
 
 PROBE_SCALE = 8       # the probe frame is 1/8 of the resolution in each direction
@@ -284,6 +285,11 @@ class ShardedRenderer:
         self.ctx.set_sample_layout(l_off, l_total)
         self.samples_total = l_total
         if self.comm.world == 1:
+            state = legacy_mt19937_state(rng) if hasattr(self.ctx, "generate_samples") else None
+            if state is not None:      # MT19937 runs on the GPU; the stream is advanced as host draws would
+                key, pos = self.ctx.generate_samples(state[1], state[2])
+                rng.set_state((state[0], key, pos) + tuple(state[3:]))
+                return g_total
             for pos in range(0, g_total, SAMPLE_CHUNK):
                 self.ctx.upload_samples(pos, rng.random(min(SAMPLE_CHUNK, g_total - pos)))
             return g_total

@@ -13,8 +13,11 @@ Phases of one frame (:class:`Renderer`):
 2. ``draw_samples()``  only for scenes with disk lights: the uniforms the
                   reference would draw from NumPy's global stream, in its order
                   (post-order over tree nodes, lights in scene order, all angles
-                  then all radii of a block - reference objects.py:132-133), are
-                  drawn with ``numpy.random.random`` and uploaded;
+                  then all radii of a block - reference objects.py:132-133).  With
+                  NumPy's legacy stream (MT19937) the generator itself runs on the GPU
+                  from the stream's current state and the state is advanced as the
+                  host draws would have advanced it; any other ``rng`` object is
+                  asked for the numbers (``rng.random(n)``) and they are uploaded;
 3. ``shade()``    lighting and bottom-up colour combination;
 4. ``image()``    read back ``(n, 3)`` float64 colours in [0, 1].
 """
@@ -29,16 +32,34 @@ DEFAULT_RAYS_PER_PIXEL = 24
 SAMPLE_CHUNK = 1 << 24  # uniforms drawn and uploaded per step (128 MiB)
 
 
+def legacy_mt19937_state(rng):
+    """``rng.get_state()`` if ``rng`` is NumPy's legacy stream on MT19937 (the ``numpy.random``
+    module or a ``RandomState``), else None."""
+    get = getattr(rng, "get_state", None)
+    if get is None:
+        return None
+    try:
+        state = get()
+    except TypeError:
+        return None
+    if isinstance(state, tuple) and len(state) >= 3 and state[0] == "MT19937":
+        return state
+    return None
+
+
 class Renderer:
     """A scene bound to one GPU; renders whole frames, row blocks or pixel lists."""
 
-    def __init__(self, scene, params=None, device=0, stream=None, rng=None, precision="mixed"):
+    def __init__(self, scene, params=None, device=0, stream=None, rng=None, precision="mixed", sampler="auto"):
         self.flat = scene if isinstance(scene, FlatScene) else flatten_scene(scene)
         if params is None:
             params = RenderParams(width=int(self.flat.pixels_x), height=int(self.flat.pixels_y))
         self.params = params
         self.tree = build_tree(params.max_reflection_depth, params.max_refraction_depth)
         self.rng = np.random if rng is None else rng
+        if sampler not in ("auto", "device", "host"):
+            raise ValueError("sampler must be 'auto', 'device' or 'host'")
+        self.sampler = sampler
         self.ctx = _native.Context(device, stream)
         self.ctx.set_scene(self.flat, params, self.tree)
         self.ctx.set_precision(precision)
@@ -97,9 +118,18 @@ class Renderer:
             raise RuntimeError("trace() must run (with check=True) before draw_samples()")
         offsets, _, total = sample_offsets(self.tree, self.flat.lights, self.node_hits, self.node_beam)
         self.ctx.set_sample_layout(offsets, total)
+        self.samples_total = total
+        state = legacy_mt19937_state(self.rng) if self.sampler != "host" else None
+        if state is not None:
+            # the generator behind the stream is MT19937 (numpy.random / RandomState): run it on
+            # the GPU and leave the stream where the host draws would have left it
+            key, pos = self.ctx.generate_samples(state[1], state[2])
+            self.rng.set_state((state[0], key, pos) + tuple(state[3:]))
+            return total
+        if self.sampler == "device":
+            raise ValueError("sampler='device' needs numpy.random or a numpy.random.RandomState on MT19937")
         for pos in range(0, total, SAMPLE_CHUNK):
             self.ctx.upload_samples(pos, self.rng.random(min(SAMPLE_CHUNK, total - pos)))
-        self.samples_total = total
         return total
 
     def shade(self):
@@ -124,7 +154,7 @@ class Renderer:
         return self.ctx.counters()
 
 
-def raytrace(scene, *, params=None, device=0, precision="mixed"):
+def raytrace(scene, *, params=None, device=0, precision="mixed", sampler="auto"):
     """Render ``scene``; returns a ``(height, width, 3)`` float64 image in [0, 1].
 
     Same meaning as the reference's ``raytrace(scene)`` (reference
@@ -138,7 +168,7 @@ def raytrace(scene, *, params=None, device=0, precision="mixed"):
     with float64 re-evaluation of every shadow decision it cannot certify;
     ``"f64"`` evaluates them in float64 like the reference.  Everything else is
     float64 in both modes."""
-    with Renderer(scene, params, device, precision=precision) as r:
+    with Renderer(scene, params, device, precision=precision, sampler=sampler) as r:
         r.begin_rows(0, r.params.height)
         img = r.render_pixels()
         return img.reshape(r.params.height, r.params.width, 3)

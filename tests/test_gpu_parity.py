@@ -302,3 +302,68 @@ def test_main_writes_png(tmp_path):
     assert px.shape == (54, 96, 4) and (px[..., 3] == 255).all()
     img = raytrace(build_scene("example_2", 96, 54))
     assert (px[..., :3] == (img * 255).astype(np.uint8)).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# NumPy's legacy generator (MT19937, random_sample) on the device.
+def _render_with(sampler, scene, state):
+    np.random.set_state(state)
+    with Renderer(scene, precision="f64", sampler=sampler) as r:
+        r.begin_rows(0, r.params.height)
+        img = r.render_pixels()
+        return img, r.samples_total, np.random.get_state()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pos", [624, 0, 1, 623, 397])
+def test_device_mt19937_equals_numpy_stream(pos):
+    """Same image as with host-drawn samples (bit for bit: the packed samples are equal) and the
+    global stream is left exactly where numpy.random.random(total) leaves it."""
+    scene = build_scene("example_4", 96, 54)
+    np.random.seed(123)
+    st = np.random.get_state()
+    st = (st[0], st[1], pos) + tuple(st[3:])
+    host_img, total, host_state = _render_with("host", scene, st)
+    dev_img, total_d, dev_state = _render_with("device", scene, st)
+    assert total == total_d and total > 100000
+    assert np.array_equal(host_img, dev_img)
+    assert dev_state[2] == host_state[2] and np.array_equal(dev_state[1], host_state[1])
+    # and the stream really continues identically
+    np.random.set_state(dev_state)
+    a = np.random.random(5)
+    np.random.set_state(host_state)
+    assert np.array_equal(a, np.random.random(5))
+
+
+@pytest.mark.gpu
+def test_device_mt19937_small_and_spot_streams():
+    """Streams shorter than one generator step, and the in-beam column addressing."""
+    for scene in (synthetic.spotlight_scene("cubic", 2, 24, 14), synthetic.spotlight_scene("linear", 16, 64, 36)):
+        np.random.seed(7)
+        st = np.random.get_state()
+        host_img, total, host_state = _render_with("host", scene, st)
+        dev_img, _, dev_state = _render_with("device", scene, st)
+        assert np.array_equal(host_img, dev_img)
+        assert dev_state[2] == host_state[2] and np.array_equal(dev_state[1], host_state[1])
+
+
+@pytest.mark.gpu
+def test_device_sampler_needs_a_legacy_stream():
+    scene = build_scene("example_4", 32, 18)
+    with Renderer(scene, rng=np.random.default_rng(0), sampler="device") as r:
+        r.begin_rows(0, 18)
+        r.trace()
+        with pytest.raises(ValueError):
+            r.draw_samples()
+    with Renderer(scene, rng=np.random.default_rng(0)) as r:      # auto: falls back to rng.random()
+        r.begin_rows(0, 18)
+        img = r.render_pixels()
+        assert np.isfinite(img).all()
+    rs = np.random.RandomState(5)
+    with Renderer(scene, rng=rs, precision="f64") as r:           # a RandomState runs on the device
+        r.begin_rows(0, 18)
+        img = r.render_pixels()
+        total = r.samples_total
+    ref = np.random.RandomState(5)
+    ref.random_sample(total)
+    assert np.array_equal(rs.get_state()[1], ref.get_state()[1]) and rs.get_state()[2] == ref.get_state()[2]
