@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "mt_jump.h"
 #include "rt_kernels.hip"
 
 using namespace rt;
@@ -122,7 +123,7 @@ struct RtContext {
     DevBuf<unsigned long long> work;
     double* user_image = nullptr;
     DevBuf<uint8_t> image8;
-    DevBuf<uint32_t> mt_ring, mt_raw;
+    DevBuf<uint32_t> mt_ring, mt_raw, mt_polys;
     DevBuf<long long> mt_end;
     uint8_t* user_image8 = nullptr;
     int32_t* user_batches = nullptr;
@@ -305,7 +306,7 @@ void rt_destroy(RtContext* ctx) {
     ctx->info.release(); ctx->link.release(); ctx->list_ray.release(); ctx->redo_list.release(); ctx->list_node.release(); ctx->lvl_shade_base.release();
     for (auto& b : ctx->list_j) b.release();
     ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->packed32.release(); ctx->staging.release();
-    ctx->image.release(); ctx->image8.release(); ctx->mt_ring.release(); ctx->mt_raw.release(); ctx->mt_end.release(); ctx->sample_off.release(); ctx->work.release();
+    ctx->image.release(); ctx->image8.release(); ctx->mt_ring.release(); ctx->mt_raw.release(); ctx->mt_polys.release(); ctx->mt_end.release(); ctx->sample_off.release(); ctx->work.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -598,37 +599,80 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         *pos_out = pos;
         return RT_OK;
     }
-    // x[0..624) is the caller's key block, the first output consumed is x[pos]
+    // Absolute word indices: x[0..624) is the caller's key block, the first output consumed is
+    // x[pos], the first one not consumed x[next].
+    const long long next = (long long)pos + 2 * total;
+    // streams of L = 2^ell words, at most ~1024 of them
+    int ell = 16;
+    while (((next + (1ll << ell) - 1) >> ell) > 1024) ++ell;
+    const long long L = 1ll << ell;
+    const int T = (int)((next + L - 1) >> ell);
+    // words held in memory at a time (whole streams); RT_MT_RAW_WORDS overrides for tests
+    long long budget = 1ll << 32;
+    if (const char* e = getenv("RT_MT_RAW_WORDS")) budget = std::max(1ll, atoll(e));
+    const int per_pass = (int)std::max<long long>(1, std::min<long long>(T, budget >> ell));
+
+    HIP_TRY(ctx->mt_ring.ensure((size_t)(T + 1) * MT_RING));
+    HIP_TRY(ctx->mt_end.ensure((size_t)T + 1));
+    HIP_TRY(ctx->mt_raw.ensure((size_t)per_pass * L + 2));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::vector<uint32_t> ring(MT_RING, 0u);
     memcpy(ring.data(), key, MT_N * sizeof(uint32_t));
-    long long gen_end = MT_N;
-    constexpr long long CHUNK = 1ll << 25;              // doubles per piece (256 MiB of raw words)
-    HIP_TRY(ctx->mt_ring.ensure(MT_RING));
-    HIP_TRY(ctx->mt_end.ensure(1));
-    HIP_TRY(ctx->mt_raw.ensure((size_t)std::min(CHUNK, total) * 2));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const long long first_end = MT_N;
     HIP_TRY(hipMemcpy(ctx->mt_ring.p, ring.data(), MT_RING * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->mt_end.p, &gen_end, sizeof gen_end, hipMemcpyHostToDevice));
-    const Dev D = ctx->dev();
-    const int64_t pack_blocks = std::max<int64_t>(1, std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB));
-    for (long long a = 0; a < total; a += CHUNK) {
-        const long long n = std::min(CHUNK, total - a);
-        hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, ctx->mt_raw.p,
-                           (long long)pos + 2 * a, 2 * n, 0ll);
-        if (ctx->pack_E > 0)
-            hipLaunchKernelGGL((k_pack<GeneratedStream>), dim3((unsigned)pack_blocks), dim3(BLOCK), 0, ctx->stream, D,
-                               GeneratedStream{ctx->mt_raw.p}, (int64_t)a, (int64_t)n);
+    HIP_TRY(hipMemcpy(ctx->mt_end.p, &first_end, sizeof first_end, hipMemcpyHostToDevice));
+
+    if (T > 1) {
+        // start windows of streams 1 .. T-1 by jump-ahead from the window at L - 1, which a
+        // scratch copy of stream 0 (ring T) reaches sequentially
+        int n_polys = 1;                                   // bits of T - 2, the largest t - 1
+        while (((T - 2) >> n_polys) > 0) ++n_polys;
+        std::vector<uint32_t> polys((size_t)n_polys * MT_N);
+        for (int b = 0; b < n_polys; ++b)
+            if (!mtjump::pow2_words(ell + b, polys.data() + (size_t)b * MT_N))
+                return fail(RT_ERR_INVALID, "MT19937 jump tables unavailable (stream too long?)");
+        HIP_TRY(ctx->mt_polys.ensure(polys.size()));
+        HIP_TRY(hipMemcpy(ctx->mt_polys.p, polys.data(), polys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->mt_ring.p + (size_t)T * MT_RING, ring.data(), MT_RING * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->mt_end.p + T, &first_end, sizeof first_end, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, (uint32_t*)nullptr,
+                           T, ell, 0ll, 0ll, T, L - 1 + MT_N);
+        hipLaunchKernelGGL(k_mt_jump, dim3(T - 1), dim3(640), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, T, 0ll,
+                           ctx->mt_polys.p, n_polys, ell);
     }
     // The state NumPy would be left in: the key block that holds the last word consumed and
     // the position after it (a position of 624 means "regenerate at the next draw").
-    const long long next = (long long)pos + 2 * total;     // first word not consumed
     const long long block = (next - 1) / MT_N;
-    hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, ctx->mt_raw.p,
-                       0ll, 0ll, (block + 1) * MT_N);
+    const int last_stream = T - 1;
+    const Dev D = ctx->dev();
+    const int64_t pack_blocks = std::max<int64_t>(1, std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB));
+    for (int t0 = 0; t0 < T; t0 += per_pass) {
+        const int n_streams = std::min(per_pass, T - t0);
+        const long long w_lo = (long long)t0 << ell;                                   // first word of the pass
+        const long long w_hi = std::min(((long long)(t0 + n_streams) << ell) + 1, next); // one past its last word
+        hipLaunchKernelGGL(k_mt_generate, dim3(n_streams), dim3(256), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, ctx->mt_raw.p,
+                           t0, ell, w_lo, w_hi, last_stream, (block + 1) * MT_N);
+        // values whose two words both lie in [w_lo, w_hi): value p uses words pos + 2p, pos + 2p + 1
+        const long long p_lo = w_lo <= pos ? 0 : (w_lo - pos + 1) / 2;
+        const long long p_hi = (w_hi - 2 - pos) / 2;                                   // inclusive
+        if (ctx->pack_E > 0 && p_hi >= p_lo && w_hi - 2 - pos >= 0)
+            hipLaunchKernelGGL((k_pack<GeneratedStream>), dim3((unsigned)pack_blocks), dim3(BLOCK), 0, ctx->stream, D,
+                               GeneratedStream{ctx->mt_raw.p + (pos + 2 * p_lo - w_lo)}, (int64_t)p_lo, (int64_t)(p_hi - p_lo + 1));
+    }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ring.data(), ctx->mt_ring.p, MT_RING * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    // the block may begin in the stream before the last one
+    std::vector<uint32_t> prev_ring(MT_RING, 0u);
+    HIP_TRY(hipMemcpyAsync(ring.data(), ctx->mt_ring.p + (size_t)last_stream * MT_RING, MT_RING * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    if (last_stream > 0)
+        HIP_TRY(hipMemcpyAsync(prev_ring.data(), ctx->mt_ring.p + (size_t)(last_stream - 1) * MT_RING, MT_RING * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < MT_N; ++i) key_out[i] = ring[(block * MT_N + i) & (MT_RING - 1)];
+    const long long last_first = (long long)last_stream << ell;
+    for (int i = 0; i < MT_N; ++i) {
+        const long long n = block * MT_N + i;
+        key_out[i] = (n >= last_first ? ring : prev_ring)[n & (MT_RING - 1)];
+    }
     *pos_out = (int32_t)(next - block * MT_N);
     return RT_OK;
 }

@@ -1155,8 +1155,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 struct GeneratedStream {
     const uint32_t* raw;   // raw[2 i], raw[2 i + 1]: untempered words of stream[a + i]
     __device__ __forceinline__ double operator()(int64_t i) const {
-        const uint2 w = reinterpret_cast<const uint2*>(raw)[i];
-        const uint32_t hi = mt_temper(w.x) >> 5, lo = mt_temper(w.y) >> 6;
+        const uint32_t hi = mt_temper(raw[2 * i]) >> 5, lo = mt_temper(raw[2 * i + 1]) >> 6;
         return ((double)hi * 67108864.0 + (double)lo) / 9007199254740992.0;
     }
 };
@@ -1211,22 +1210,39 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, 
 //   ring[2048]  x[n] at slot n & 2047 for the last 2048 indices below *gen_end (in and out)
 //   raw[i]      receives x[raw_first + i] for 0 <= i < raw_n (untempered)
 //   generates until *gen_end >= max(raw_first + raw_n, gen_until)
+//
+// Streams: the word sequence is cut into streams of L = 2^ell words; stream t covers the
+// absolute word indices [t L, (t+1) L] (one word of overlap, a value may be built from the
+// last word of one stream and the first of the next) and has its own ring and counter.
+// Stream 0 starts from the caller's key block, the others from windows k_mt_jump made.
 constexpr int MT_N = 624, MT_M = 397, MT_STEP = MT_N - MT_M, MT_RING = 2048;
 __device__ __forceinline__ uint32_t mt_twist(uint32_t lo, uint32_t hi) {
     const uint32_t y = (lo & 0x80000000u) | (hi & 0x7fffffffu);
     return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
-__global__ __launch_bounds__(256) void k_mt_generate(uint32_t* ring_g, long long* gen_end_g, uint32_t* raw,
-                                                     long long raw_first, long long raw_n, long long gen_until) {
+// grid: one workgroup per stream t = t0 + blockIdx.x.
+//   raw[w - raw_origin] receives x[w] for the stream's words below w_end
+//   the stream with index last_stream keeps generating until its counter reaches gen_until
+__global__ __launch_bounds__(256) void k_mt_generate(uint32_t* rings, long long* gen_ends, uint32_t* raw, int t0, int ell,
+                                                     long long raw_origin, long long w_end, int last_stream,
+                                                     long long gen_until) {
     __shared__ uint32_t ring[MT_RING];
     const int tid = threadIdx.x;
+    const int t = t0 + blockIdx.x;
+    uint32_t* ring_g = rings + (size_t)t * MT_RING;
     for (int i = tid; i < MT_RING; i += 256) ring[i] = ring_g[i];
-    const long long g0 = *gen_end_g;
-    const long long raw_end = raw_first + raw_n;
-    const long long target = raw_end > gen_until ? raw_end : gen_until;
+    const long long g0 = gen_ends[t];
+    const long long raw_first = (long long)t << ell;
+    long long raw_end = ((long long)(t + 1) << ell) + 1;
+    if (raw_end > w_end) raw_end = w_end;
+    if (!raw || raw_end < raw_first) raw_end = raw_first;
+    const long long raw_n = raw_end - raw_first;
+    long long target = raw_n > 0 ? raw_end : g0;
+    if (t == last_stream && gen_until > target) target = gen_until;
+    uint32_t* out = raw ? raw + (raw_first - raw_origin) : nullptr;
     __syncthreads();
     // words of the window that exist already
-    for (long long n = raw_first + tid; n < raw_end && n < g0; n += 256) raw[n - raw_first] = ring[n & (MT_RING - 1)];
+    for (long long n = raw_first + tid; n < raw_end && n < g0; n += 256) out[n - raw_first] = ring[n & (MT_RING - 1)];
     // two steps per iteration (all four twist operands were written before the previous
     // barrier); positions as 32-bit offsets from g0
     const long long todo = target > g0 ? target - g0 : 0;
@@ -1246,8 +1262,8 @@ __global__ __launch_bounds__(256) void k_mt_generate(uint32_t* ring_g, long long
             const uint32_t x1 = x0 ^ mt_twist(lo1, hi1);
             ring[s0] = x0;
             ring[s1] = x1;
-            if (rel >= 0 && rel < raw_n) raw[rel] = x0;
-            if (rel + MT_STEP >= 0 && rel + MT_STEP < raw_n) raw[rel + MT_STEP] = x1;
+            if (rel >= 0 && rel < raw_n) out[rel] = x0;
+            if (rel + MT_STEP >= 0 && rel + MT_STEP < raw_n) out[rel + MT_STEP] = x1;
             prev = x1;
         }
         slot = (slot + 2 * MT_STEP) & (MT_RING - 1);
@@ -1255,7 +1271,78 @@ __global__ __launch_bounds__(256) void k_mt_generate(uint32_t* ring_g, long long
         __syncthreads();
     }
     for (int i = tid; i < MT_RING; i += 256) ring_g[i] = ring[i];
-    if (tid == 0) *gen_end_g = g0 + (long long)iters * 2 * MT_STEP;
+    if (tid == 0) gen_ends[t] = g0 + (long long)iters * 2 * MT_STEP;
+}
+
+// Jump-ahead.  Workgroup blockIdx.x makes the start window of stream t = blockIdx.x + 1:
+// the window at word index t L - 1, reached from the base window (index L - 1, taken from
+// ring `base_ring` whose counter is base_end) by applying, for every set bit b of t - 1, the
+// polynomial x^(L 2^b) mod phi:  new window word j = XOR over set coefficients i of s[i + j],
+// s the sequence generated from the current window.  The low 31 bits of the new window's
+// first word are not meaningful (nothing reads them: that word belongs to the previous
+// stream).  polys: [n_polys][624] coefficient words, polys[b] = x^(L 2^b) mod phi.
+constexpr int MTJ_RING = 4096, MTJ_CHUNK = 8 * MT_STEP;   // coefficients consumed per round
+__global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen_ends, int base_ring, long long base_end,
+                                                 const uint32_t* polys, int n_polys, int ell) {
+    __shared__ uint32_t xs[MTJ_RING];     // s[i] at slot i & 4095
+    __shared__ uint32_t coef[MT_N];
+    __shared__ uint32_t win[MT_N];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x + 1;
+    const long long L = 1ll << ell;
+    // base window = x[L-1 .. L+622]
+    for (int j = tid; j < MT_N; j += 640) win[j] = rings[(size_t)base_ring * MT_RING + ((L - 1 + j) & (MT_RING - 1))];
+    (void)base_end;
+    __syncthreads();
+    for (int b = 0; b < n_polys; ++b) {
+        if (!(((unsigned)(t - 1) >> b) & 1u)) continue;      // uniform
+        for (int j = tid; j < MT_N; j += 640) {
+            xs[j] = win[j];
+            coef[j] = polys[(size_t)b * MT_N + j];
+        }
+        __syncthreads();
+        uint32_t acc = 0;
+        uint32_t prev = (tid < MT_STEP) ? xs[MT_N - MT_STEP + tid] : 0u;   // own-chain value s[gen - 227 + tid]
+        int gen = MT_N;                                                     // s[0 .. gen) exist
+        for (int c0 = 0; c0 < 19937; c0 += MTJ_CHUNK) {
+            // make s available up to c0 + MTJ_CHUNK + 623
+            while (gen < c0 + MTJ_CHUNK + MT_N) {
+                if (tid < MT_STEP) {
+                    const int n0 = gen + tid, n1 = n0 + MT_STEP;
+                    const uint32_t x0 = prev ^ mt_twist(xs[(n0 - MT_N) & (MTJ_RING - 1)], xs[(n0 - MT_N + 1) & (MTJ_RING - 1)]);
+                    const uint32_t x1 = x0 ^ mt_twist(xs[(n1 - MT_N) & (MTJ_RING - 1)], xs[(n1 - MT_N + 1) & (MTJ_RING - 1)]);
+                    xs[n0 & (MTJ_RING - 1)] = x0;
+                    xs[n1 & (MTJ_RING - 1)] = x1;
+                    prev = x1;
+                }
+                gen += 2 * MT_STEP;
+                __syncthreads();
+            }
+            // accumulate the coefficients c0 .. c0 + MTJ_CHUNK
+            if (tid < MT_N) {
+                const int c1 = min(c0 + MTJ_CHUNK, 19937);
+                for (int w = c0 >> 5; w <= (c1 - 1) >> 5; ++w) {
+                    uint32_t bits = __builtin_amdgcn_readfirstlane(coef[w]);
+                    // keep only coefficients inside [c0, c1)
+                    const int lo = w << 5;
+                    if (lo < c0) bits &= ~0u << (c0 - lo);
+                    if (lo + 32 > c1) bits &= ~0u >> (lo + 32 - c1);
+                    while (bits) {
+                        const int i = lo + __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        acc ^= xs[(i + tid) & (MTJ_RING - 1)];
+                    }
+                }
+            }
+            __syncthreads();   // the next round overwrites ring slots this round read
+        }
+        if (tid < MT_N) win[tid] = acc;
+        __syncthreads();
+    }
+    // the stream's ring: window word j is x[t L - 1 + j]
+    const long long first = (long long)t * L - 1;
+    for (int j = tid; j < MT_N; j += 640) rings[(size_t)t * MT_RING + ((first + j) & (MT_RING - 1))] = win[j];
+    if (tid == 0) gen_ends[t] = first + MT_N;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -367,3 +367,23 @@ def test_device_sampler_needs_a_legacy_stream():
     ref = np.random.RandomState(5)
     ref.random_sample(total)
     assert np.array_equal(rs.get_state()[1], ref.get_state()[1]) and rs.get_state()[2] == ref.get_state()[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("raw_words", [None, 1 << 17, 1 << 16])
+def test_device_mt19937_streams_and_passes(monkeypatch, raw_words):
+    """A stream long enough for two dozen jump-ahead streams; with a small raw-word budget
+    they are generated in several passes (a value may straddle two passes)."""
+    if raw_words is None:
+        monkeypatch.delenv("RT_MT_RAW_WORDS", raising=False)
+    else:
+        monkeypatch.setenv("RT_MT_RAW_WORDS", str(raw_words))
+    scene = build_scene("example_4", 160, 90)
+    np.random.seed(2024)
+    st = np.random.get_state()
+    st = (st[0], st[1], 311) + tuple(st[3:])        # odd position: values straddle stream boundaries
+    host_img, total, host_state = _render_with("host", scene, st)
+    dev_img, _, dev_state = _render_with("device", scene, st)
+    assert 2 * total > 20 * 65536
+    assert np.array_equal(host_img, dev_img)
+    assert dev_state[2] == host_state[2] and np.array_equal(dev_state[1], host_state[1])
