@@ -215,7 +215,18 @@ int rt_upload_samples(RtContext *ctx, int64_t dst_offset, const double *u, int64
  * numpy.random.random(total) would produce it (reference objects.py:132-133 consumes that
  * stream), and key_out / pos_out receive the state those draws leave behind (for
  * numpy.random.set_state), so the caller's stream continues as in the reference.
- * Single-context frames only: the layout must be the whole image's. */
+ * A context that renders only part of the image (row blocks on several GPUs) first tells
+ * where its columns sit in the whole image's stream: per (node, light) the block's offset
+ * there, the whole image's number of (in-beam) hits and the rank of this context's first hit
+ * among them (rt_set_sample_layout_global, after rt_set_sample_layout; `total` = length of
+ * the whole stream).  Every context then generates the whole stream and keeps its columns,
+ * and all of them return the same final state. */
+/* Host only: the coefficients (bit i = coefficient of x^i, 624 words) of x^(2^k) mod the
+ * characteristic polynomial of MT19937's one-word step - the jump-ahead polynomials
+ * rt_generate_samples uses to start its parallel streams.  0 <= k < 48. */
+int rt_mt19937_jump_poly(int32_t k, uint32_t *out624);
+int rt_set_sample_layout_global(RtContext *ctx, const int64_t *offsets, const int64_t *columns,
+                                const int64_t *first_column /* each [n_nodes][RT_MAX_LIGHTS] */, int64_t total);
 int rt_generate_samples(RtContext *ctx, const uint32_t *key /* [624] */, int32_t pos,
                         uint32_t *key_out /* [624] */, int32_t *pos_out);
 

@@ -90,6 +90,8 @@ SIGNATURES = {
     "rt_get_node_counts": (C.c_int, [_P, _I64P, _I64P, _I64P]),
     "rt_set_sample_layout": (C.c_int, [_P, _I64P, C.c_int64]),
     "rt_upload_samples": (C.c_int, [_P, C.c_int64, _F64P, C.c_int64]),
+    "rt_mt19937_jump_poly": (C.c_int, [C.c_int32, C.POINTER(C.c_uint32)]),
+    "rt_set_sample_layout_global": (C.c_int, [_P, _I64P, _I64P, _I64P, C.c_int64]),
     "rt_generate_samples": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "rt_set_precision": (C.c_int, [_P, C.c_int32]),
     "rt_shade": (C.c_int, [_P]),
@@ -145,6 +147,13 @@ def _ptr(a, ctype):
 def _vec3(dst, src):
     for i in range(3):
         dst[i] = float(src[i])
+
+
+def mt19937_jump_poly(k):
+    """Coefficient words of x^(2^k) mod MT19937's characteristic polynomial (host computation)."""
+    out = np.empty(624, dtype=np.uint32)
+    _check(load_library().rt_mt19937_jump_poly(int(k), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return out
 
 
 def build_tree_native(max_reflection_depth, max_refraction_depth):
@@ -277,6 +286,15 @@ class Context:
     def upload_samples(self, dst_offset, u):
         u = _f64(u).reshape(-1)
         _check(self.lib.rt_upload_samples(self._h, int(dst_offset), _ptr(u, C.c_double), u.size))
+
+    def set_sample_layout_global(self, offsets, columns, first_column, total):
+        """Where this context's columns sit in the whole image's stream (see the header)."""
+        def full(a, fill):
+            out = np.full((self.n_nodes, RT_MAX_LIGHTS), fill, dtype=np.int64)
+            out[:, :a.shape[1]] = a
+            return out
+        o, c, f = full(np.asarray(offsets), -1), full(np.asarray(columns), 0), full(np.asarray(first_column), 0)
+        _check(self.lib.rt_set_sample_layout_global(self._h, _ptr(o, C.c_int64), _ptr(c, C.c_int64), _ptr(f, C.c_int64), int(total)))
 
     def generate_samples(self, key, pos):
         """Generate the whole sample stream on the device from a legacy MT19937 state

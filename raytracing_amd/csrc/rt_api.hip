@@ -119,7 +119,9 @@ struct RtContext {
     bool have_packed32 = false;
     int64_t pack_base[RT_MAX_LIGHTS] = {0};
     int64_t pack_E = 0;
-    DevBuf<int64_t> sample_off;
+    DevBuf<int64_t> sample_off, sample_global;
+    bool have_global_layout = false;
+    int64_t global_total = 0;
     DevBuf<unsigned long long> work;
     double* user_image = nullptr;
     DevBuf<uint8_t> image8;
@@ -158,7 +160,7 @@ struct RtContext {
         D.spot_mask = spot_mask;
         D.X = explicit_xy ? X.p : nullptr; D.Y = explicit_xy ? Y.p : nullptr;
         D.row0 = row0; D.npix = (int32_t)npix;
-        D.packed = packed.p; D.packed32 = have_packed32 ? packed32.p : nullptr; D.pack_E = pack_E; D.sample_off = sample_off.p;
+        D.packed = packed.p; D.packed32 = have_packed32 ? packed32.p : nullptr; D.pack_E = pack_E; D.sample_off = sample_off.p; D.sample_global = have_global_layout ? sample_global.p : nullptr;
         for (int l = 0; l < RT_MAX_LIGHTS; ++l) D.pack_base[l] = pack_base[l];
         D.image = user_image ? user_image : image.p;
         return D;
@@ -306,7 +308,7 @@ void rt_destroy(RtContext* ctx) {
     ctx->info.release(); ctx->link.release(); ctx->list_ray.release(); ctx->redo_list.release(); ctx->list_node.release(); ctx->lvl_shade_base.release();
     for (auto& b : ctx->list_j) b.release();
     ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->packed32.release(); ctx->staging.release();
-    ctx->image.release(); ctx->image8.release(); ctx->mt_ring.release(); ctx->mt_raw.release(); ctx->mt_polys.release(); ctx->mt_end.release(); ctx->sample_off.release(); ctx->work.release();
+    ctx->image.release(); ctx->image8.release(); ctx->mt_ring.release(); ctx->mt_raw.release(); ctx->mt_polys.release(); ctx->mt_end.release(); ctx->sample_off.release(); ctx->sample_global.release(); ctx->work.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -565,6 +567,23 @@ int rt_set_sample_layout(RtContext* ctx, const int64_t* offsets, int64_t total) 
     ctx->pack_E = entries;
     ctx->sample_total = total;
     ctx->layout_set = true;
+    ctx->have_global_layout = false;
+    return RT_OK;
+}
+
+int rt_set_sample_layout_global(RtContext* ctx, const int64_t* offsets, const int64_t* columns, const int64_t* first_column,
+                                int64_t total) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->layout_set) return fail(RT_ERR_STATE, "rt_set_sample_layout has not been called");
+    if (!offsets || !columns || !first_column || total < 0) return fail(RT_ERR_INVALID, "bad whole-image sample layout");
+    const size_t n = (size_t)ctx->tree.n_nodes() * RT_MAX_LIGHTS;
+    HIP_TRY(ctx->sample_global.ensure(3 * n));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(ctx->sample_global.p, offsets, n * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->sample_global.p + n, columns, n * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->sample_global.p + 2 * n, first_column, n * sizeof(int64_t), hipMemcpyHostToDevice));
+    ctx->have_global_layout = true;
+    ctx->global_total = total;
     return RT_OK;
 }
 
@@ -593,7 +612,8 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     if (!ctx->layout_set) return fail(RT_ERR_STATE, "rt_set_sample_layout has not been called");
     if (!key || !key_out || !pos_out) return fail(RT_ERR_INVALID, "null argument");
     if (pos < 0 || pos > MT_N) return fail(RT_ERR_INVALID, "MT19937 position %d out of range", pos);
-    const long long total = ctx->sample_total;          // doubles; two 32-bit outputs each
+    // doubles to draw (two 32-bit outputs each): the whole image's stream
+    const long long total = ctx->have_global_layout ? ctx->global_total : ctx->sample_total;
     if (total == 0) {
         memcpy(key_out, key, MT_N * sizeof(uint32_t));
         *pos_out = pos;
@@ -674,6 +694,12 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         key_out[i] = (n >= last_first ? ring : prev_ring)[n & (MT_RING - 1)];
     }
     *pos_out = (int32_t)(next - block * MT_N);
+    return RT_OK;
+}
+
+int rt_mt19937_jump_poly(int32_t k, uint32_t* out624) {
+    if (!out624) return fail(RT_ERR_INVALID, "out624 is null");
+    if (!mtjump::pow2_words(k, out624)) return fail(RT_ERR_INVALID, "no jump polynomial for 2^%d words", k);
     return RT_OK;
 }
 

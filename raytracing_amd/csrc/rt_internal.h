@@ -113,6 +113,10 @@ struct Dev {
     int64_t pack_base[RT_MAX_LIGHTS];
     int64_t pack_E;             // entries of the shading list when the samples were packed
     const int64_t* sample_off;  // [K][RT_MAX_LIGHTS] offset of each (node, light) block in the caller's stream
+    // optional, for samples generated on the device when this context renders a part of the
+    // image: where the block sits in the whole image's stream ([3][K][RT_MAX_LIGHTS]: offset,
+    // columns of the whole image, first column of this context), or null
+    const int64_t* sample_global;
     // output
     double* image;  // [npix][3]
 };

@@ -1139,6 +1139,7 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int64_t entr
 // (entry-major within a sample, so k_surface reads it fully coalesced).
 // Source of stream values for k_pack: doubles the caller uploaded ...
 struct UploadedStream {
+    static constexpr bool WHOLE_IMAGE = false;   // positions are in this context's own stream
     const double* chunk;   // chunk[i] = stream[a + i]
     __device__ __forceinline__ double operator()(int64_t i) const { return chunk[i]; }
 };
@@ -1153,6 +1154,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 struct GeneratedStream {
+    static constexpr bool WHOLE_IMAGE = true;    // positions are in the whole image's stream when the layout says so
     const uint32_t* raw;   // raw[2 i], raw[2 i + 1]: untempered words of stream[a + i]
     __device__ __forceinline__ double operator()(int64_t i) const {
         const uint32_t hi = mt_temper(raw[2 * i]) >> 5, lo = mt_temper(raw[2 * i + 1]) >> 6;
@@ -1181,8 +1183,17 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, 
                 jj = D.list_j[0][e];
             }
             const int N = Lt.n_points;
-            const int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
-            if (off < 0 || off + 2 * N * h <= a || off >= b) continue;
+            int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
+            if (off < 0) continue;
+            if (Stream::WHOLE_IMAGE && D.sample_global) {
+                // this context holds columns [first column, + h) of a block that is wider in the
+                // whole image's stream
+                const size_t KL = (size_t)D.K * RT_MAX_LIGHTS, at = (size_t)node * RT_MAX_LIGHTS + l;
+                off = D.sample_global[at];
+                h = D.sample_global[KL + at];
+                jj += D.sample_global[2 * KL + at];
+            }
+            if (off + 2 * N * h <= a || off >= b) continue;
             double* dst = D.packed + 2 * (D.pack_base[l] + e);
             float* dst32 = D.packed32 ? D.packed32 + 2 * (D.pack_base[l] + e) : nullptr;
             for (int part = 0; part < 2; ++part) {

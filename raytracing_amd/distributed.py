@@ -293,6 +293,18 @@ class ShardedRenderer:
             for pos in range(0, g_total, SAMPLE_CHUNK):
                 self.ctx.upload_samples(pos, rng.random(min(SAMPLE_CHUNK, g_total - pos)))
             return g_total
+        state = legacy_mt19937_state(rng) if hasattr(self.ctx, "generate_samples") else None
+        if state is not None:
+            # every rank runs the generator over the whole image's stream on its GPU and keeps
+            # the columns of its own hits; all ranks leave their streams in the same state
+            first = np.zeros_like(g_cnt)
+            for l, light in enumerate(lights):
+                per_rank = self.rank_beam[:, :, l] if light.kind == LIGHT_SPOT else self.rank_hits
+                first[:, l] = per_rank[:r].sum(axis=0)
+            self.ctx.set_sample_layout_global(g_off, g_cnt, first, g_total)
+            key, pos = self.ctx.generate_samples(state[1], state[2])
+            rng.set_state((state[0], key, pos) + tuple(state[3:]))
+            return g_total
         for node in self.tree.post_order():
             for l, light in enumerate(lights):
                 h = int(g_cnt[node, l])

@@ -93,3 +93,32 @@ def test_sample_offsets_follow_post_order():
     disk = [FlatLight(LIGHT_DISK, np.zeros(3), 1.0, np.ones(3), np.ones(3), n_points=3)]
     off, cnt, total = sample_offsets(t, disk, hits, beam)
     assert total == 2 * 3 * hits.sum()
+
+
+@pytest.mark.parametrize("k", [5, 16])
+def test_mt19937_jump_polynomial_advances_the_window(k):
+    """g = x^(2^k) mod phi applied to a window of the word sequence (XOR of the windows
+    at the set coefficients) is the window 2^k words later."""
+    g = _native.mt19937_jump_poly(k)
+    bits = np.flatnonzero(np.unpackbits(g.view(np.uint8), bitorder="little"))
+    assert bits.max() < 19937
+    if k == 5:
+        assert list(bits) == [32]             # below the degree the power of x is not reduced
+    # an independent word sequence: MT19937 recurrence in NumPy
+    x = np.empty(2 ** k + 19937 + 2 * 624 + 100, dtype=np.uint32)
+    x[:624] = np.random.RandomState(99).get_state()[1]
+    for n in range(624, x.size):
+        y = (x[n - 624] & np.uint32(0x80000000)) | (x[n - 623] & np.uint32(0x7FFFFFFF))
+        x[n] = x[n - 227] ^ (y >> np.uint32(1)) ^ (np.uint32(0x9908B0DF) if y & np.uint32(1) else np.uint32(0))
+    n0 = 37
+    acc = np.zeros(624, dtype=np.uint32)
+    for i in bits:
+        acc ^= x[n0 + i:n0 + i + 624]
+    want = x[n0 + 2 ** k:n0 + 2 ** k + 624]
+    assert np.array_equal(acc[1:], want[1:])
+    assert (acc[0] ^ want[0]) & np.uint32(0x80000000) == 0     # only the top bit of word 0 is state
+
+
+def test_mt19937_jump_polynomial_range():
+    with pytest.raises(_native.RtError):
+        _native.mt19937_jump_poly(48)

@@ -37,7 +37,13 @@ def _worker(rank, world, port, name, w, h, out_path):
         r = ShardedRenderer(build_scene(name, w, h), None, comm, ctx)
         bounds = r.choose_rows()
         r.trace_checked()
-        r.draw_samples()
+        total = r.draw_samples()
+        # the samples come from the generator running on the GPU over the whole image's stream;
+        # every rank's NumPy stream must be where numpy.random.random(total) would leave it
+        want = np.random.RandomState(0)
+        want.random_sample(total)
+        got = np.random.get_state()
+        assert got[2] == want.get_state()[2] and np.array_equal(got[1], want.get_state()[1])
         r.shade()
         r0, r1 = r.my_rows
         tile = torch.from_numpy(ctx.read_image()[:(r1 - r0) * w].copy())
