@@ -18,7 +18,7 @@ constexpr int MAX_LEVEL_NODES = 1024; // widest level of the static ray tree we 
 constexpr int MAX_NODES = 65536;
 constexpr int SPH_CHUNK_LARGE = 512;  // spheres staged in LDS per pass of the nearest-hit loop
 constexpr int SPH_CHUNK_SMALL = 64;   // ... for scenes with few spheres (less LDS, more resident workgroups)
-constexpr int SHADE_LDS_SPHERES = 512;
+constexpr int SHADE_LDS_SPHERES = 128; // sphere and material tables of the lighting kernels kept in LDS up to this many
 
 // counters
 enum { C_T = 0, C_I = 1, C_R = 2, C_HIT = 3, C_BEAM0 = 4, C_SHADE = 4 + RT_MAX_LIGHTS,

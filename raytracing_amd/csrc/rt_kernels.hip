@@ -837,6 +837,12 @@ __global__ __launch_bounds__(BLOCK) void k_link(Dev D, int level) {
 // ---------------------------------------------------------------------------------------------
 // Shading helpers.
 
+struct SurfaceMaterial {  // what the surface colour needs of a sphere's material
+    double ambient[3], kdiff[3], kspec[3], shininess;
+};
+__device__ __forceinline__ SurfaceMaterial surface_material(const double* m) {
+    return {{m[0], m[1], m[2]}, {m[3], m[4], m[5]}, {m[6], m[7], m[8]}, m[9]};
+}
 struct ShadowSphere {  // what a shadow ray needs of a sphere
     double cx, cy, cz, r2, tr, kr, kg, kb;  // k = attenuation coefficient * absorption colour
 };
@@ -969,6 +975,19 @@ struct HitSphere {
 // set of occluders that reaches the image always equals the float64 path's.  Samples are
 // fetched eight at a time so that their loads are in flight together.
 constexpr int SAMPLE_BATCH = 8;
+// Two samples per lane at a time: the straight-line float arithmetic runs on packed
+// instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), only the transcendental
+// functions, the clamps and the decisions are per sample.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f vfma(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, (v2f)(b), c); }
+__device__ __forceinline__ v2f vfma(v2f a, float b, float c) { return __builtin_elementwise_fma(a, (v2f)(b), (v2f)(c)); }
+__device__ __forceinline__ v2f vclip01(v2f a) { return {fclip01(a.x), fclip01(a.y)}; }
+struct F3x2 {
+    v2f x, y, z;
+};
+__device__ __forceinline__ v2f vdot(F3 a, F3x2 b) { return vfma(b.z, a.z, vfma(b.y, a.y, b.x * a.x)); }
+
 template <bool LDS>
 __device__ void disk_light_mixed(const Dev& D, const ShadowSphere* s_sh, const RtLight& Lt, const float* pk,
                                  int64_t stride, V3 Pb, V3 d, V3 n, V3 kdiff, V3 kspec,
@@ -997,79 +1016,117 @@ __device__ void disk_light_mixed(const Dev& D, const ShadowSphere* s_sh, const R
     const F3 dcol = f3(ld3(Lt.diffuse_color)), scol = f3(ld3(Lt.specular_color));
     const float Rf = (float)Lt.radius, per_sample = (float)(Lt.intensity / Lt.n_points), shf = (float)shin;
     const float frame = sqrtf(fmaxf(fdot(xh, xh), fdot(yh, yh)));  // the disk frame is not normalised
+    const float eL_scale = 1.5e-6f * Rf * frame;
     const int N = Lt.n_points;
-    F3 aId = {0, 0, 0}, aIs = {0, 0, 0}, aKd = {0, 0, 0}, aKs = {0, 0, 0};
-    for (int s0 = 0; s0 < N; s0 += SAMPLE_BATCH) {
-        float ut[SAMPLE_BATCH], ur[SAMPLE_BATCH];
+    F3x2 aId = {0, 0, 0}, aIs = {0, 0, 0}, aKd = {0, 0, 0}, aKs = {0, 0, 0};
+    // Transmittance of the occluders of one sample (reference objects.py:274-285) as one
+    // exponential per channel: the product over spheres of tr * exp(-k * chord) is
+    // exp2(sum of log2(tr) - k * log2(e) * chord), chord = 2 sqrt(disc) for an origin outside
+    // the sphere and 0 inside.  The per-sphere constants are the same in every lane.
+    auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    float lt[SREG], k2r[SREG], k2g[SREG], k2b[SREG];
 #pragma unroll
-        for (int k = 0; k < SAMPLE_BATCH; ++k) {
-            const float2 u = *reinterpret_cast<const float2*>(pk + (int64_t)min(s0 + k, N - 1) * stride);
-            ut[k] = u.x;
-            ur[k] = u.y;
+    for (int i = 0; i < SREG; ++i) {
+        lt[i] = k2r[i] = k2g[i] = k2b[i] = 0;
+        if (i < S) {
+            const ShadowSphere sp = LDS ? s_sh[i]
+                                        : ShadowSphere{0, 0, 0, 0, D.mat[i * RT_MAT_WIDTH + 11],
+                                                       D.mat[i * RT_MAT_WIDTH + 14] * D.mat[i * RT_MAT_WIDTH + 15],
+                                                       D.mat[i * RT_MAT_WIDTH + 14] * D.mat[i * RT_MAT_WIDTH + 16],
+                                                       D.mat[i * RT_MAT_WIDTH + 14] * D.mat[i * RT_MAT_WIDTH + 17]};
+            lt[i] = uniform(__builtin_amdgcn_logf((float)sp.tr));           // log2; -inf for an opaque sphere
+            k2r[i] = uniform(-2.0f * 1.4426950408889634f * (float)sp.kr);
+            k2g[i] = uniform(-2.0f * 1.4426950408889634f * (float)sp.kg);
+            k2b[i] = uniform(-2.0f * 1.4426950408889634f * (float)sp.kb);
         }
+    }
+    auto occlude = [&](int i, float disc, F3& e) {
+        const float sq = hs[i].C > 0 ? __builtin_amdgcn_sqrtf(disc) : 0.0f;
+        e.x = fmaf(k2r[i], sq, e.x + lt[i]);
+        e.y = fmaf(k2g[i], sq, e.y + lt[i]);
+        e.z = fmaf(k2b[i], sq, e.z + lt[i]);
+    };
+    for (int s0 = 0; s0 < N; s0 += SAMPLE_BATCH) {
+        float2 u[SAMPLE_BATCH];
 #pragma unroll
-        for (int k = 0; k < SAMPLE_BATCH; ++k) {
+        for (int k = 0; k < SAMPLE_BATCH; ++k)
+            u[k] = *reinterpret_cast<const float2*>(pk + (int64_t)min(s0 + k, N - 1) * stride);
+#pragma unroll
+        for (int k = 0; k < SAMPLE_BATCH; k += 2) {
             if (s0 + k >= N) break;
-            const float sn = __builtin_amdgcn_sinf(ut[k]), cs = __builtin_amdgcn_cosf(ut[k]);  // argument in revolutions
-            const float rad = __builtin_amdgcn_sqrtf(ur[k]) * Rf;
-            F3 Lv = {fmaf(rad, fmaf(cs, xh.x, sn * yh.x), q.x), fmaf(rad, fmaf(cs, xh.y, sn * yh.y), q.y),
-                     fmaf(rad, fmaf(cs, xh.z, sn * yh.z), q.z)};
-            const float d2 = fdot(Lv, Lv);
-            const float inv = __builtin_amdgcn_rsqf(d2);
-            const F3 Lh = {Lv.x * inv, Lv.y * inv, Lv.z * inv};
+            const bool both = s0 + k + 1 < N;    // with an odd sample count the last pair is half empty
+            const v2f ut = {u[k].x, u[k + 1].x}, ur = {u[k].y, u[k + 1].y};
+            // angle in revolutions
+            const v2f sn = {__builtin_amdgcn_sinf(ut.x), __builtin_amdgcn_sinf(ut.y)};
+            const v2f cs = {__builtin_amdgcn_cosf(ut.x), __builtin_amdgcn_cosf(ut.y)};
+            const v2f rad = (v2f){__builtin_amdgcn_sqrtf(ur.x), __builtin_amdgcn_sqrtf(ur.y)} * Rf;
+            const F3x2 Lv = {vfma(rad, vfma(cs, xh.x, sn * yh.x), (v2f)(q.x)), vfma(rad, vfma(cs, xh.y, sn * yh.y), (v2f)(q.y)),
+                             vfma(rad, vfma(cs, xh.z, sn * yh.z), (v2f)(q.z))};
+            const v2f d2 = vfma(Lv.z, Lv.z, vfma(Lv.y, Lv.y, Lv.x * Lv.x));
+            const v2f inv = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
+            const F3x2 Lh = {Lv.x * inv, Lv.y * inv, Lv.z * inv};
             // bound of |Lh - exact unit light vector|: light point (sin/cos 1.3e-7, u -> float
             // 3.8e-7 rad, sqrt 1e-7, all times the disk radius) over the distance, plus rounding
-            const float eL = fmaf(1.5e-6f * Rf * frame, inv, 6e-7f);
-            F3 mult = {1, 1, 1};
-            bool unsure = false;
+            const v2f eL = vfma(inv, eL_scale, 6e-7f);
+            F3 e0 = {0, 0, 0}, e1 = {0, 0, 0};   // log2 of the transmittance
+            bool unsure0 = false, unsure1 = false, hit0 = false, hit1 = false;
 #pragma unroll
             for (int i = 0; i < SREG; ++i) {
                 if (i < S) {
-                    const float b = fdot(hs[i].oc, Lh);
-                    const float disc = fmaf(b, b, -hs[i].C);
-                    const float db = hs[i].len * eL;
-                    const float m = fmaf(2.0f * fabsf(b), db, fmaf(db, db, hs[i].k0));
-                    if (fabsf(disc) <= m) {
-                        unsure = true;
-                    } else if (disc > 0 && (b < 0 || hs[i].C < 0)) {
-                        const ShadowSphere sp = LDS ? s_sh[i]
-                                                    : ShadowSphere{0, 0, 0, 0, D.mat[i * RT_MAT_WIDTH + 11],
-                                                                   D.mat[i * RT_MAT_WIDTH + 14] * D.mat[i * RT_MAT_WIDTH + 15],
-                                                                   D.mat[i * RT_MAT_WIDTH + 14] * D.mat[i * RT_MAT_WIDTH + 16],
-                                                                   D.mat[i * RT_MAT_WIDTH + 14] * D.mat[i * RT_MAT_WIDTH + 17]};
-                        const float tr = (float)sp.tr;
-                        const float chord = hs[i].C > 0 ? 2.0f * __builtin_amdgcn_sqrtf(disc) : 0.0f;
-                        mult.x *= tr * fexp(-(float)sp.kr * chord);
-                        mult.y *= tr * fexp(-(float)sp.kg * chord);
-                        mult.z *= tr * fexp(-(float)sp.kb * chord);
-                    }
+                    const v2f b = vdot(hs[i].oc, Lh);
+                    const v2f disc = vfma(b, b, (v2f)(-hs[i].C));
+                    const v2f db = eL * hs[i].len;
+                    const v2f ab2 = (v2f){fabsf(b.x), fabsf(b.y)} * 2.0f;
+                    const v2f m = vfma(ab2, db, vfma(db, db, (v2f)(hs[i].k0)));
+                    if (fabsf(disc.x) <= m.x) unsure0 = true;
+                    else if (disc.x > 0 && (b.x < 0 || hs[i].C < 0)) { occlude(i, disc.x, e0); hit0 = true; }
+                    if (fabsf(disc.y) <= m.y) unsure1 = true;
+                    else if (disc.y > 0 && (b.y < 0 || hs[i].C < 0)) { occlude(i, disc.y, e1); hit1 = true; }
                 }
             }
-            if (unsure) n_unsure += 1;
-            const float fall = per_sample * inv * inv;
-            aId.x += fclip01(fall * dcol.x * mult.x); aId.y += fclip01(fall * dcol.y * mult.y); aId.z += fclip01(fall * dcol.z * mult.z);
-            aIs.x += fclip01(fall * scol.x * mult.x); aIs.y += fclip01(fall * scol.y * mult.y); aIs.z += fclip01(fall * scol.z * mult.z);
-            const float nl = fdot(nf, Lh);
-            const float two_nl = 2.0f * nl;
-            const F3 Rv = {fmaf(-two_nl, nf.x, Lh.x), fmaf(-two_nl, nf.y, Lh.y), fmaf(-two_nl, nf.z, Lh.z)};
-            const float rd = fabsf(fdot(Rv, df));
-            const float p = shf == 0 ? 1.0f : __builtin_amdgcn_exp2f(shf * __builtin_amdgcn_logf(rd));
-            aKd.x += fclip01(nl * kdf.x); aKd.y += fclip01(nl * kdf.y); aKd.z += fclip01(nl * kdf.z);
-            aKs.x += fclip01(p * ksf.x); aKs.y += fclip01(p * ksf.y); aKs.z += fclip01(p * ksf.z);
+            if (unsure0) n_unsure += 1;
+            if (unsure1 && both) n_unsure += 1;
+            F3 mult0 = {1, 1, 1}, mult1 = {1, 1, 1};
+            if (hit0) mult0 = {__builtin_amdgcn_exp2f(e0.x), __builtin_amdgcn_exp2f(e0.y), __builtin_amdgcn_exp2f(e0.z)};
+            if (hit1) mult1 = {__builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y), __builtin_amdgcn_exp2f(e1.z)};
+            const F3x2 mult = {{mult0.x, mult1.x}, {mult0.y, mult1.y}, {mult0.z, mult1.z}};
+            const v2f fall = inv * inv * per_sample;
+            const v2f nl = vdot(nf, Lh);
+            const v2f two_nl = nl * 2.0f;
+            const F3x2 Rv = {vfma(-two_nl, nf.x, Lh.x), vfma(-two_nl, nf.y, Lh.y), vfma(-two_nl, nf.z, Lh.z)};
+            const v2f rdv = vdot(df, Rv);
+            v2f p = {1.0f, 1.0f};
+            if (shf != 0)
+                p = (v2f){__builtin_amdgcn_exp2f(shf * __builtin_amdgcn_logf(fabsf(rdv.x))),
+                          __builtin_amdgcn_exp2f(shf * __builtin_amdgcn_logf(fabsf(rdv.y)))};
+            F3x2 cId = {vclip01(fall * dcol.x * mult.x), vclip01(fall * dcol.y * mult.y), vclip01(fall * dcol.z * mult.z)};
+            F3x2 cIs = {vclip01(fall * scol.x * mult.x), vclip01(fall * scol.y * mult.y), vclip01(fall * scol.z * mult.z)};
+            F3x2 cKd = {vclip01(nl * kdf.x), vclip01(nl * kdf.y), vclip01(nl * kdf.z)};
+            F3x2 cKs = {vclip01(p * ksf.x), vclip01(p * ksf.y), vclip01(p * ksf.z)};
+            if (!both) {
+                const v2f first = {1.0f, 0.0f};
+                cId.x *= first; cId.y *= first; cId.z *= first; cIs.x *= first; cIs.y *= first; cIs.z *= first;
+                cKd.x *= first; cKd.y *= first; cKd.z *= first; cKs.x *= first; cKs.y *= first; cKs.z *= first;
+            }
+            aId.x += cId.x; aId.y += cId.y; aId.z += cId.z;
+            aIs.x += cIs.x; aIs.y += cIs.y; aIs.z += cIs.z;
+            aKd.x += cKd.x; aKd.y += cKd.y; aKd.z += cKd.z;
+            aKs.x += cKs.x; aKs.y += cKs.y; aKs.z += cKs.z;
+            __builtin_amdgcn_sched_barrier(0);   // one pair at a time: interleaving pairs costs registers
         }
     }
-    sumId = v3(aId); sumIs = v3(aIs); sumKd = v3(aKd); sumKs = v3(aKs);
+    auto total = [](F3x2 v) -> V3 { return {(double)(v.x.x + v.x.y), (double)(v.y.x + v.y.y), (double)(v.z.x + v.z.y)}; };
+    sumId = total(aId); sumIs = total(aIs); sumKd = total(aKd); sumKs = total(aKs);
 }
 
 // Surface colour of one hit under all lights (reference raytrace.py:136-152,
 // :215-234 and objects.py:94-235).  entry: index of the hit in the shading list,
 // which is also the index of its disk-light samples in the packed sample buffer.
 template <bool LDS, bool MIXED>
-__device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int64_t entry, uint32_t info, V3 Pb, V3 d, V3 n,
-                            const double* m, unsigned& n_samples, unsigned& n_fallback) {
-    const SceneConst& sc = *D.sc;
-    const V3 kdiff = ld3(m + 3), kspec = ld3(m + 6);
-    const double shin = m[9];
+__device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphere* s_sh, int64_t entry, uint32_t info,
+                            V3 Pb, V3 d, V3 n, const SurfaceMaterial& mat, unsigned& n_samples, unsigned& n_fallback) {
+    const V3 kdiff = ld3(mat.kdiff), kspec = ld3(mat.kspec);
+    const double shin = mat.shininess;
     V3 surf = {0, 0, 0};
     for (int l = 0; l < D.n_lights; ++l) {
         const RtLight& Lt = sc.lights[l];
@@ -1125,7 +1182,7 @@ __device__ V3 surface_color(const Dev& D, const ShadowSphere* s_sh, int64_t entr
         }
         surf = surf + clip01(sumKd * Id + sumKs * Is);
     }
-    surf = surf + clip01(ld3(m) * ld3(sc.ambient));
+    surf = surf + clip01(ld3(mat.ambient) * ld3(sc.ambient));
     return clip01(surf);
 }
 
@@ -1360,33 +1417,47 @@ __global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen
 // Lighting for the dense list of hits whose surface colour matters (all levels).
 template <bool LDS, bool MIXED>
 __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(Dev D) {
-    __shared__ ShadowSphere s_sh[LDS ? SHADE_LDS_SPHERES : 1];
+    constexpr int TABLE = MIXED ? SREG : (LDS ? SHADE_LDS_SPHERES : 1);   // the float32 pass is for S <= SREG
+    __shared__ ShadowSphere s_sh[TABLE];
+    __shared__ SurfaceMaterial s_mat[TABLE];
+    __shared__ double s_centre[TABLE][3];
+    __shared__ SceneConst s_sc;
     __shared__ unsigned s_work[3];
     const int tid = threadIdx.x;
     if (D.flags[0]) return;  // arena overflow: the frame is invalid, the host reports it
     if (tid < 3) s_work[tid] = 0;
+    for (int i = tid; i < (int)(sizeof(SceneConst) / 8); i += BLOCK)
+        reinterpret_cast<double*>(&s_sc)[i] = reinterpret_cast<const double*>(D.sc)[i];
     if (LDS) {
         for (int i = tid; i < D.S; i += BLOCK) {
             const double* g = D.geom + (size_t)i * 4;
             const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
             s_sh[i] = {g[0], g[1], g[2], g[3] * g[3], m[11], m[14] * m[15], m[14] * m[16], m[14] * m[17]};
+            s_mat[i] = surface_material(m);
+            s_centre[i][0] = g[0]; s_centre[i][1] = g[1]; s_centre[i][2] = g[2];
         }
     }
     __syncthreads();
-    const double eps = D.sc->eps;
+    const SceneConst& sc = s_sc;
+    const double eps = sc.eps;
     const int total = D.lvl_shade_base[D.n_levels];
+    const int stride = gridDim.x * BLOCK;
     unsigned my_hits = 0, my_samples = 0, my_fallback = 0;
-    for (int e = blockIdx.x * BLOCK + tid; e < total; e += gridDim.x * BLOCK) {
-        const uint32_t ray = D.list_ray[e];
+    int e = blockIdx.x * BLOCK + tid;
+    uint32_t ray = e < total ? D.list_ray[e] : 0u;
+    while (e < total) {
+        // the next entry's ray index is in flight while this one is shaded
+        const int e_next = e + stride;
+        const uint32_t ray_next = e_next < total ? D.list_ray[e_next] : 0u;
         const uint32_t info = D.info[ray];
-        const int sid = info & I_SID_MASK;
-        const double* g = D.geom + (size_t)sid * 4;
-        const double* m = D.mat + (size_t)sid * RT_MAT_WIDTH;
         V3 P = {D.px[ray], D.py[ray], D.pz[ray]};
         V3 d = {D.dx[ray], D.dy[ray], D.dz[ray]};
-        const Surface sf = surface_at(P, ld3(g), info & I_INSIDE, eps);
+        const int sid = info & I_SID_MASK;
+        const V3 centre = LDS ? V3{s_centre[sid][0], s_centre[sid][1], s_centre[sid][2]} : ld3(D.geom + (size_t)sid * 4);
+        const SurfaceMaterial mat = LDS ? s_mat[sid] : surface_material(D.mat + (size_t)sid * RT_MAT_WIDTH);
+        const Surface sf = surface_at(P, centre, info & I_INSIDE, eps);
         unsigned unsure = 0;
-        V3 surf = surface_color<LDS, MIXED>(D, s_sh, e, info, sf.Pb, d, sf.n, m, my_samples, unsure);
+        V3 surf = surface_color<LDS, MIXED>(D, sc, s_sh, e, info, sf.Pb, d, sf.n, mat, my_samples, unsure);
         my_hits += 1;
         D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
         if (MIXED && unsure) {
@@ -1394,6 +1465,8 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
             my_fallback += unsure;
             D.redo_list[atomicAdd(&D.flags[1], 1)] = (uint32_t)e;
         }
+        e = e_next;
+        ray = ray_next;
     }
     if (my_hits) {
         atomicAdd(&s_work[0], my_hits);
@@ -1420,7 +1493,8 @@ __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
         }
     }
     __syncthreads();
-    const double eps = D.sc->eps;
+    const SceneConst& sc = *D.sc;
+    const double eps = sc.eps;
     for (int i = blockIdx.x * BLOCK + tid; i < total; i += gridDim.x * BLOCK) {
         const int64_t e = D.redo_list[i];
         const uint32_t ray = D.list_ray[e];
@@ -1430,7 +1504,8 @@ __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
         V3 d = {D.dx[ray], D.dy[ray], D.dz[ray]};
         const Surface sf = surface_at(P, ld3(D.geom + (size_t)sid * 4), info & I_INSIDE, eps);
         unsigned a = 0, b = 0;
-        V3 surf = surface_color<LDS, false>(D, s_sh, e, info, sf.Pb, d, sf.n, D.mat + (size_t)sid * RT_MAT_WIDTH, a, b);
+        V3 surf = surface_color<LDS, false>(D, sc, s_sh, e, info, sf.Pb, d, sf.n,
+                                            surface_material(D.mat + (size_t)sid * RT_MAT_WIDTH), a, b);
         D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
     }
 }
