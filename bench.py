@@ -105,11 +105,16 @@ def main():
                          "so that kernel durations are free of overlap)")
     args = ap.parse_args()
 
+    if os.environ.get("RT_BENCH_WATCHDOG"):     # dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
     import torch
     from raytracing_amd.distributed import FrameJob, init_group
 
     rank, world, group = init_group(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if "RT_BENCH_DEVICE" in os.environ:      # rehearsal of several ranks on one GPU
+        local_rank = int(os.environ["RT_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     W, H = args.width, args.height
 

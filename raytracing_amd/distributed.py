@@ -117,7 +117,9 @@ def init_group(n_gpus):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # RT_DIST_BACKEND overrides the choice (rehearsing several ranks on one GPU needs gloo:
+        # RCCL refuses two ranks on the same device)
+        backend = os.environ.get("RT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size(), dist.group.WORLD
 
@@ -415,7 +417,12 @@ class FrameJob:
         self.ctx = _native.Context(device, self.stream.cuda_stream)
         self.precision = precision
         self.r = ShardedRenderer(scene, params, self.comm, self.ctx)
-        if world > 1:
+        # Batch sizes stay on the GPU between levels when the collectives are RCCL's (stream
+        # ordered, no host round trip).  RT_BATCH_EXCHANGE=host|device overrides; gloo moves
+        # device tensors through the host anyway and gets the host-synchronised exchange.
+        import torch.distributed as dist
+        mode = os.environ.get("RT_BATCH_EXCHANGE") or ("device" if world > 1 and dist.get_backend(group) == "nccl" else "host")
+        if world > 1 and mode == "device":
             with torch.cuda.stream(self.stream):
                 self.r.batch_tensor = torch.zeros(self.r.tree.n_nodes, dtype=torch.int32, device=self.device)
         self.width, self.height = width, height
