@@ -51,15 +51,16 @@ F_ISECT, F_HIT, F_LIGHT, F_SHADOW = 22, 100, 50, 24
 
 
 def cpu_baseline(seconds_budget=25.0):
-    """Time the NumPy float64 oracle on this host: example_1-3 at 500x500 (the
-    reference's default size) as long as the budget allows."""
+    """Time the NumPy float64 oracle on this host: example_1-3 at 800x800 (about 15 s of
+    CPU work; the oracle's throughput does not depend on the image size) as long as
+    the budget allows."""
     from oracle import numpy_oracle
     from raytracing_amd.Scenes.scenes import build_scene
     rays, spent, used = 0, 0.0, []
     for name in SCENES[:3]:
         if spent > seconds_budget:
             break
-        scene = build_scene(name, 500, 500)
+        scene = build_scene(name, 800, 800)
         t0 = time.perf_counter()
         _, stats = numpy_oracle.render(scene, seed=0)
         spent += time.perf_counter() - t0
@@ -67,7 +68,7 @@ def cpu_baseline(seconds_budget=25.0):
         used.append(name)
     threads = int(os.environ.get("OPENBLAS_NUM_THREADS", os.environ.get("OMP_NUM_THREADS", "0")) or 0)
     return {"value": rays / spent / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"NumPy float64 oracle, {'+'.join(used)} at 500x500, {rays} rays in {spent:.1f} s "
+            "sample": f"NumPy float64 oracle, {'+'.join(used)} at 800x800, {rays} rays in {spent:.1f} s "
                       f"(NumPy elementwise code is single-threaded; BLAS threads setting {threads or 'default'}, "
                       f"host has {os.cpu_count()} logical CPUs)"}
 
