@@ -1,6 +1,7 @@
 // Host side of the C ABI declared in include/raytracing_amd.h: context, memory,
 // launch sequence.  The kernels are compiled into the same translation unit.
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -104,6 +105,8 @@ struct RtContext {
     int S = 0;
 
     DevBuf<double> geom, mat, fres;
+    DevBuf<float> cull;
+    double cull_ref[3] = {0, 0, 0};
     DevBuf<SceneConst> sc;
     DevBuf<int32_t> node_a, node_b, node_branch, node_child, level_start;
     DevBuf<int32_t> node_n, node_nglobal, node_hits, node_beam, node_tile0, node_ntiles, lvl_ntiles, lvl_tilebase, flags;
@@ -145,7 +148,7 @@ struct RtContext {
 
     Dev dev() const {
         Dev D{};
-        D.geom = geom.p; D.mat = mat.p; D.fres = fres.p; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
+        D.geom = geom.p; D.mat = mat.p; D.fres = fres.p; D.cull = cull.p; D.cull_ref[0] = cull_ref[0]; D.cull_ref[1] = cull_ref[1]; D.cull_ref[2] = cull_ref[2]; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
         D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
         D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
@@ -297,7 +300,7 @@ void rt_destroy(RtContext* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->collect();
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
-    ctx->geom.release(); ctx->mat.release(); ctx->fres.release(); ctx->sc.release();
+    ctx->geom.release(); ctx->mat.release(); ctx->fres.release(); ctx->cull.release(); ctx->sc.release();
     ctx->node_a.release(); ctx->node_b.release(); ctx->node_branch.release(); ctx->node_child.release();
     ctx->level_start.release(); ctx->node_n.release(); ctx->node_nglobal.release(); ctx->node_hits.release();
     ctx->node_beam.release(); ctx->node_tile0.release(); ctx->node_ntiles.release(); ctx->lvl_ntiles.release();
@@ -378,6 +381,25 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
             fres[i * 4 + 3] = 0;
         }
         HIP_TRY(hipMemcpy(ctx->fres.p, fres.data(), S * 4 * sizeof(double), hipMemcpyHostToDevice));
+        // reference point of the float32 screening: centroid of the spheres that are not huge
+        double sum[3] = {0, 0, 0};
+        size_t cnt = 0;
+        for (size_t i = 0; i < S; ++i) {
+            const double* g = scene->sphere_geom + i * 4;
+            if (fabs(g[3]) > 1e4) continue;
+            sum[0] += g[0]; sum[1] += g[1]; sum[2] += g[2];
+            ++cnt;
+        }
+        for (int k = 0; k < 3; ++k) ctx->cull_ref[k] = cnt ? sum[k] / (double)cnt : 0.0;
+        // float32 screening table for the shadow tests of scenes with many spheres
+        const size_t n_pairs = ((S + 7) / 8) * 4;
+        std::vector<CullPair> cull(n_pairs);
+        for (size_t i = 0; i < n_pairs * 2; ++i) {
+            if (i < S) cull_entry(cull[i >> 1], (int)(i & 1), scene->sphere_geom + i * 4);
+            else cull_blank(cull[i >> 1], (int)(i & 1));
+        }
+        HIP_TRY(ctx->cull.ensure(n_pairs * 10));
+        HIP_TRY(hipMemcpy(ctx->cull.p, cull.data(), n_pairs * sizeof(CullPair), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemcpy(ctx->sc.p, &sc, sizeof sc, hipMemcpyHostToDevice));
     HIP_TRY(ctx->node_a.ensure(K)); HIP_TRY(ctx->node_b.ensure(K)); HIP_TRY(ctx->node_branch.ensure(K));

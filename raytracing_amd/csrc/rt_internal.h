@@ -16,7 +16,7 @@ constexpr int NCNT = RT_NUM_COUNTERS; // per-tile counters: 3 child kinds, hits,
 constexpr int MAX_LEVELS = 32;
 constexpr int MAX_LEVEL_NODES = 1024; // widest level of the static ray tree we accept
 constexpr int MAX_NODES = 65536;
-constexpr int SPH_CHUNK_LARGE = 512;  // spheres staged in LDS per pass of the nearest-hit loop
+constexpr int SPH_CHUNK_LARGE = 256;  // spheres staged in LDS per pass of the nearest-hit loop
 constexpr int SPH_CHUNK_SMALL = 64;   // ... for scenes with few spheres (less LDS, more resident workgroups)
 constexpr int SHADE_LDS_SPHERES = 128; // sphere and material tables of the lighting kernels kept in LDS up to this many
 
@@ -59,6 +59,8 @@ struct Dev {
     const SceneConst* sc;
     int32_t S;
     int32_t n_lights;
+    double cull_ref[3];  // a point in the middle of the (moderately sized) spheres, see the float32 screening
+    const float* cull;   // [ceil(S / 8) * 4][10] float32 screening table, two spheres per entry (CullPair)
     // static tree
     const int32_t* node_a;
     const int32_t* node_b;

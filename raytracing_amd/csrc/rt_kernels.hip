@@ -92,6 +92,53 @@ __device__ __forceinline__ V3 normalize(V3 v) {
     return {quotient(v.x, len, r), quotient(v.y, len, r), quotient(v.z, len, r)};
 }
 
+// Pairs of floats: arithmetic on them compiles to the packed float32 instructions
+// (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32), two results per lane and instruction.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f vfma(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, (v2f)(b), c); }
+__device__ __forceinline__ v2f vfma(v2f a, float b, float c) { return __builtin_elementwise_fma(a, (v2f)(b), (v2f)(c)); }
+
+// ---- float32 screening of ray-sphere pairs ------------------------------------------------
+// With many spheres nearly every (ray, sphere) pair is a clear miss.  The distance of the
+// sphere's centre from the ray's line is first evaluated in float32 for two spheres at a time:
+// oc = c - o, b = oc.d, p = oc - b d, and the pair is a certain miss when |p| > r + E.  E bounds
+// the error of the computed |p|: with u = 2^-24 and N = |o|_1 + |c|_1 (which also bounds |oc| and
+// |b|), each component of oc is off by at most 2 u N (rounding of o, c and of the difference), b
+// by 6.5 u N, b d_k by 7.5 u N, the fma that forms p_k adds 2 u N: 11.5 u N per component,
+// 20 u N in length; the table uses 1.5e-6 N (25 u N) and a radius enlarged by 2e-6 r for the
+// roundings of |p|^2, of the sum and of the comparison.  The reference's own float64 rounding of
+// its discriminant corresponds to 1e-16 N^2 / r in this length, far inside E.  Only pairs that
+// are not certain misses take the float64 test, which alone decides.
+struct CullPair {   // two spheres, component-wise
+    float cx[2], cy[2], cz[2], r[2], e[2];
+};
+__host__ __device__ __forceinline__ void cull_entry(CullPair& p, int k, const double* g) {
+    p.cx[k] = (float)g[0]; p.cy[k] = (float)g[1]; p.cz[k] = (float)g[2];
+    p.r[k] = (float)(fabs(g[3]) * 1.000002);
+    p.e[k] = 1.5e-6f * (float)((fabs(g[0]) + fabs(g[1]) + fabs(g[2])) * 1.000001);
+}
+__host__ __device__ __forceinline__ void cull_blank(CullPair& p, int k) {   // never passes the screening
+    p.cx[k] = p.cy[k] = p.cz[k] = 0.0f;
+    p.cx[k] = 1.0e15f;   // far away; the caller also ignores indices beyond the table's end
+    p.r[k] = 0.0f;
+    p.e[k] = 0.0f;
+}
+__device__ __forceinline__ float cull_ray_margin(V3 o) {
+    return 1.5e-6f * (float)((fabs(o.x) + fabs(o.y) + fabs(o.z)) * 1.000001);
+}
+// Positive: the ray's line certainly misses the sphere.  One value per sphere of the pair.
+__device__ __forceinline__ v2f cull_test(const CullPair& p, float ox, float oy, float oz, float dx, float dy, float dz,
+                                         float e_ray) {
+    const v2f ocx = (v2f){p.cx[0], p.cx[1]} - ox, ocy = (v2f){p.cy[0], p.cy[1]} - oy, ocz = (v2f){p.cz[0], p.cz[1]} - oz;
+    const v2f b = vfma(ocz, dz, vfma(ocy, dy, ocx * dx));
+    const v2f px = vfma(-b, dx, ocx), py = vfma(-b, dy, ocy), pz = vfma(-b, dz, ocz);
+    const v2f p2 = vfma(pz, pz, vfma(py, py, px * px));
+    const v2f t = (v2f){p.r[0], p.r[1]} + ((v2f){p.e[0], p.e[1]} + e_ray);
+    return vfma(-t, t, p2);
+}
+
+constexpr int CAND_MAX = 16;   // survivors a lane collects before the wave tests them
 // Number of set bits of a wave ballot below the calling lane.
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
@@ -263,6 +310,8 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
     __shared__ NodeRec s_node[MAX_LEVEL_NODES];
     __shared__ double s_sph[SPH_CHUNK][4];
     __shared__ SphereRec s_rec[SMALL ? SPH_CHUNK_SMALL : 1];
+    __shared__ CullPair s_cull[SMALL ? 1 : SPH_CHUNK_LARGE / 2];
+    __shared__ uint16_t s_cand[SMALL ? 1 : WPB][SMALL ? 1 : 64][CAND_MAX];   // per lane: spheres the screening kept
     __shared__ SceneConst s_sc;
     static_assert(sizeof(SceneConst) % 8 == 0, "SceneConst is copied in 8-byte words");
 
@@ -433,10 +482,56 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
                 for (int i = tid; i < cn; i += BLOCK) {
                     const double* g = D.geom + (size_t)(c0 + i) * 4;
                     s_sph[i][0] = g[0]; s_sph[i][1] = g[1]; s_sph[i][2] = g[2]; s_sph[i][3] = g[3] * g[3];
+                    cull_entry(s_cull[i >> 1], i & 1, g);
                 }
+                for (int i = cn + tid; i < ((cn + 7) & ~7); i += BLOCK) cull_blank(s_cull[i >> 1], i & 1);
                 __syncthreads();
             }
-            if (active) {
+            if (!SMALL && active) {
+                // float32 screening, two spheres per step; the float64 test only for the pairs
+                // it cannot rule out (in sphere order: ties go to the later sphere)
+                // the screening looks at the ray's whole line, so any point of the line can stand in
+                // for the origin: the one nearest to the middle of the spheres keeps the float32
+                // coordinates (and with them the error bound) small for rays that start far away
+                const V3 ref = {D.cull_ref[0], D.cull_ref[1], D.cull_ref[2]};
+                const V3 on = o + dot(ref - o, d) * d;
+                const float ox = (float)on.x, oy = (float)on.y, oz = (float)on.z;
+                const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+                const float q_ray = cull_ray_margin(on);   // this ray's part of the error bound
+                auto exact = [&](int i) {
+                    double lo, hi;
+                    if (sphere_roots(o, d, d_o, s_sph[i][0], s_sph[i][1], s_sph[i][2], s_sph[i][3], lo, hi)) {
+                        const double tt = lo > 0 ? lo : hi;
+                        if (tt > 0 && tt <= best) { best = tt; sid = c0 + i; }
+                    }
+                };
+                // The survivors of a lane go to its own short list first and are tested together
+                // afterwards: lanes survive at different spheres, testing on the spot would run the
+                // float64 code once per sphere that any lane of the wave keeps.
+                uint16_t* mine = s_cand[wave][lane];
+                int n_mine = 0;
+                auto flush = [&]() {
+                    for (int k = 0; __ballot(k < n_mine) != 0; ++k)   // the longest list of the active lanes
+                        if (k < n_mine) exact(mine[k]);
+                    n_mine = 0;
+                };
+                // four pairs per step: their table reads are issued together (the table is padded
+                // with blank entries to a multiple of eight spheres)
+                const int np = ((cn + 7) >> 3) << 2;
+                for (int p = 0; p < np; p += 4) {
+                    v2f t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = cull_test(s_cull[p + k], ox, oy, oz, dx, dy, dz, q_ray);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (!(t[k].x > 0) && 2 * (p + k) < cn) mine[n_mine++] = (uint16_t)(2 * (p + k));
+                        if (!(t[k].y > 0) && 2 * (p + k) + 1 < cn) mine[n_mine++] = (uint16_t)(2 * (p + k) + 1);
+                    }
+                    if (__ballot(n_mine > CAND_MAX - 8) != 0) flush();   // some lane's list is nearly full
+                }
+                flush();
+            }
+            if (SMALL && active) {
                 // two spheres per iteration: two independent dependency chains in flight
                 int i = 0;
                 for (; i + 1 < cn; i += 2) {
@@ -866,10 +961,68 @@ __device__ __forceinline__ double pow_shininess(double x, double sh) {
 // with a positive far root multiplies by transparency * exp(-k * chord), whether or
 // not it lies beyond the light.
 template <bool LDS>
-__device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere* s_sh, V3 o, V3 d) {
+__device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere* s_sh, uint16_t* cand, V3 o, V3 d) {
     V3 mult = {1, 1, 1};
     const int S = D.S;
     const double d_o = dot(d, o);
+    if (!LDS) {
+        // many spheres: float32 screening first (see cull_test), the float64 test for the
+        // survivors of this lane, in sphere order
+        typedef const __attribute__((address_space(4))) CullPair* ConstCull;   // uniform reads through the scalar unit
+        ConstCull table = (ConstCull)(uintptr_t)D.cull;
+        const V3 ref = {D.cull_ref[0], D.cull_ref[1], D.cull_ref[2]};
+        const V3 on = o + dot(ref - o, d) * d;
+        const float ox = (float)on.x, oy = (float)on.y, oz = (float)on.z;
+        const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+        const float e_ray = cull_ray_margin(on);
+        int n_mine = 0;
+        bool opaque = false;
+        auto flush = [&]() {
+            for (int k = 0; __ballot(k < n_mine) != 0; ++k) {   // the longest list of the active lanes
+                if (k < n_mine && !opaque) {
+                    const int i = cand[k];
+                    const double* g = D.geom + (size_t)i * 4;
+                    double lo, hi;
+                    if (sphere_roots(o, d, d_o, g[0], g[1], g[2], g[3] * g[3], lo, hi) && hi > 0) {
+                        const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
+                        const double tr = m[11];
+                        if (tr == 0) {
+                            opaque = true;
+                        } else {
+                            const double chord = lo > 0 ? hi - lo : 0.0;
+                            mult.x *= tr * exp(-(m[14] * m[15]) * chord);
+                            mult.y *= tr * exp(-(m[14] * m[16]) * chord);
+                            mult.z *= tr * exp(-(m[14] * m[17]) * chord);
+                        }
+                    }
+                }
+            }
+            n_mine = 0;
+        };
+        const int np = ((S + 7) >> 3) << 2;
+        for (int p = 0; p < np; p += 4) {
+            v2f t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                CullPair cp;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    cp.cx[w] = table[p + k].cx[w]; cp.cy[w] = table[p + k].cy[w]; cp.cz[w] = table[p + k].cz[w];
+                    cp.r[w] = table[p + k].r[w]; cp.e[w] = table[p + k].e[w];
+                }
+                t[k] = cull_test(cp, ox, oy, oz, dx, dy, dz, e_ray);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(t[k].x > 0) && 2 * (p + k) < S) cand[n_mine++] = (uint16_t)(2 * (p + k));
+                if (!(t[k].y > 0) && 2 * (p + k) + 1 < S) cand[n_mine++] = (uint16_t)(2 * (p + k) + 1);
+            }
+            if (__ballot(n_mine > CAND_MAX - 8) != 0) flush();
+        }
+        flush();
+        if (opaque) return {0, 0, 0};
+        return mult;
+    }
     for (int i = 0; i < S; ++i) {
         ShadowSphere sp;
         if (LDS) {
@@ -921,7 +1074,7 @@ struct SampleTerms {
     V3 Id, Is, kd, ks;
 };
 template <bool LDS>
-__device__ SampleTerms disk_sample_f64(const Dev& D, const ShadowSphere* s_sh, const RtLight& Lt, double u_theta,
+__device__ SampleTerms disk_sample_f64(const Dev& D, const ShadowSphere* s_sh, uint16_t* cand, const RtLight& Lt, double u_theta,
                                        double u_rad, V3 Pb, V3 d, V3 n, V3 kdiff, V3 kspec, double shin) {
     const V3 lpos = ld3(Lt.position), xh = ld3(Lt.x_hat), yh = ld3(Lt.y_hat);
     const double theta = u_theta * 6.283185307179586;
@@ -932,7 +1085,7 @@ __device__ SampleTerms disk_sample_f64(const Dev& D, const ShadowSphere* s_sh, c
     V3 Lv = lp - Pb;
     const double dist = sqrt(dot(Lv, Lv));
     V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
-    V3 mult = shadow_multiplier<LDS>(D, s_sh, Pb, Lh);
+    V3 mult = shadow_multiplier<LDS>(D, s_sh, cand, Pb, Lh);
     const double fall = (Lt.intensity / Lt.n_points) / (dist * dist);
     SampleTerms o;
     o.Id = clip01((fall * ld3(Lt.diffuse_color)) * mult);
@@ -978,10 +1131,6 @@ constexpr int SAMPLE_BATCH = 8;
 // Two samples per lane at a time: the straight-line float arithmetic runs on packed
 // instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), only the transcendental
 // functions, the clamps and the decisions are per sample.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f vfma(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, (v2f)(b), c); }
-__device__ __forceinline__ v2f vfma(v2f a, float b, float c) { return __builtin_elementwise_fma(a, (v2f)(b), (v2f)(c)); }
 __device__ __forceinline__ v2f vclip01(v2f a) { return {fclip01(a.x), fclip01(a.y)}; }
 struct F3x2 {
     v2f x, y, z;
@@ -1123,7 +1272,7 @@ __device__ void disk_light_mixed(const Dev& D, const ShadowSphere* s_sh, const R
 // :215-234 and objects.py:94-235).  entry: index of the hit in the shading list,
 // which is also the index of its disk-light samples in the packed sample buffer.
 template <bool LDS, bool MIXED>
-__device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphere* s_sh, int64_t entry, uint32_t info,
+__device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphere* s_sh, uint16_t* cand, int64_t entry, uint32_t info,
                             V3 Pb, V3 d, V3 n, const SurfaceMaterial& mat, unsigned& n_samples, unsigned& n_fallback) {
     const V3 kdiff = ld3(mat.kdiff), kspec = ld3(mat.kspec);
     const double shin = mat.shininess;
@@ -1137,7 +1286,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
             const double d2 = dot(Lv, Lv);
             const double dist = sqrt(d2);
             V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
-            V3 mult = shadow_multiplier<LDS>(D, s_sh, Pb, Lh);
+            V3 mult = shadow_multiplier<LDS>(D, s_sh, cand, Pb, Lh);
             const double fall = Lt.intensity / (dist * dist);
             V3 Id = clip01((fall * dcol) * mult), Is = clip01((fall * scol) * mult);
             const double nl = dot(n, Lh);
@@ -1169,7 +1318,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
                                   n_fallback);
         } else {
             for (int s = 0; s < N; ++s) {
-                const SampleTerms o = disk_sample_f64<LDS>(D, s_sh, Lt, pk[s * stride], pk[s * stride + 1],
+                const SampleTerms o = disk_sample_f64<LDS>(D, s_sh, cand, Lt, pk[s * stride], pk[s * stride + 1],
                                                            Pb, d, n, kdiff, kspec, shin);
                 sumId = sumId + o.Id; sumIs = sumIs + o.Is; sumKd = sumKd + o.kd; sumKs = sumKs + o.ks;
             }
@@ -1423,6 +1572,7 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
     __shared__ double s_centre[TABLE][3];
     __shared__ SceneConst s_sc;
     __shared__ unsigned s_work[3];
+    __shared__ uint16_t s_cand[LDS ? 1 : BLOCK][CAND_MAX];   // per lane: spheres the shadow screening kept
     const int tid = threadIdx.x;
     if (D.flags[0]) return;  // arena overflow: the frame is invalid, the host reports it
     if (tid < 3) s_work[tid] = 0;
@@ -1457,7 +1607,7 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
         const SurfaceMaterial mat = LDS ? s_mat[sid] : surface_material(D.mat + (size_t)sid * RT_MAT_WIDTH);
         const Surface sf = surface_at(P, centre, info & I_INSIDE, eps);
         unsigned unsure = 0;
-        V3 surf = surface_color<LDS, MIXED>(D, sc, s_sh, e, info, sf.Pb, d, sf.n, mat, my_samples, unsure);
+        V3 surf = surface_color<LDS, MIXED>(D, sc, s_sh, LDS ? nullptr : s_cand[tid], e, info, sf.Pb, d, sf.n, mat, my_samples, unsure);
         my_hits += 1;
         D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
         if (MIXED && unsure) {
@@ -1481,6 +1631,7 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
 template <bool LDS>
 __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
     __shared__ ShadowSphere s_sh[LDS ? SHADE_LDS_SPHERES : 1];
+    __shared__ uint16_t s_cand[LDS ? 1 : BLOCK][CAND_MAX];
     const int tid = threadIdx.x;
     if (D.flags[0]) return;
     const int total = D.flags[1];
@@ -1504,7 +1655,7 @@ __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
         V3 d = {D.dx[ray], D.dy[ray], D.dz[ray]};
         const Surface sf = surface_at(P, ld3(D.geom + (size_t)sid * 4), info & I_INSIDE, eps);
         unsigned a = 0, b = 0;
-        V3 surf = surface_color<LDS, false>(D, sc, s_sh, e, info, sf.Pb, d, sf.n,
+        V3 surf = surface_color<LDS, false>(D, sc, s_sh, LDS ? nullptr : s_cand[tid], e, info, sf.Pb, d, sf.n,
                                             surface_material(D.mat + (size_t)sid * RT_MAT_WIDTH), a, b);
         D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
     }
