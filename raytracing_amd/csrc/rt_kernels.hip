@@ -306,11 +306,10 @@ struct SphereRec {   // per-sphere constants of the hit record
 
 template <bool SMALL>   // SMALL: at most SPH_CHUNK_SMALL spheres, all constants in LDS
 __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int level) {
-    constexpr int SPH_CHUNK = SMALL ? SPH_CHUNK_SMALL : SPH_CHUNK_LARGE;
+    constexpr int SPH_CHUNK = SMALL ? SPH_CHUNK_SMALL : 1;
     __shared__ NodeRec s_node[MAX_LEVEL_NODES];
     __shared__ double s_sph[SPH_CHUNK][4];
     __shared__ SphereRec s_rec[SMALL ? SPH_CHUNK_SMALL : 1];
-    __shared__ CullPair s_cull[SMALL ? 1 : SPH_CHUNK_LARGE / 2];
     __shared__ uint16_t s_cand[SMALL ? 1 : WPB][SMALL ? 1 : 64][CAND_MAX];   // per lane: spheres the screening kept
     __shared__ SceneConst s_sc;
     static_assert(sizeof(SceneConst) % 8 == 0, "SceneConst is copied in 8-byte words");
@@ -474,63 +473,62 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
         const double d_o = dot(d, o);
         double best = __builtin_inf();
         int sid = -1;
-        for (int c0 = 0; c0 < S; c0 += SPH_CHUNK) {
-            const int cn = min(SPH_CHUNK, S - c0);
-            if (!SMALL) {
-                // more spheres than one LDS chunk: the waves of the workgroup step together
-                __syncthreads();
-                for (int i = tid; i < cn; i += BLOCK) {
-                    const double* g = D.geom + (size_t)(c0 + i) * 4;
-                    s_sph[i][0] = g[0]; s_sph[i][1] = g[1]; s_sph[i][2] = g[2]; s_sph[i][3] = g[3] * g[3];
-                    cull_entry(s_cull[i >> 1], i & 1, g);
+        if (!SMALL && active) {
+            // Many spheres: float32 screening of all pairs (table read through the scalar unit,
+            // four pairs per step), the float64 test only for the pairs it cannot rule out.
+            // The screening looks at the ray's whole line, so any point of the line can stand in
+            // for the origin: the one nearest to the middle of the spheres keeps the float32
+            // coordinates (and with them the error bound) small for rays that start far away.
+            typedef const __attribute__((address_space(4))) CullPair* ConstCull;
+            ConstCull table = (ConstCull)(uintptr_t)D.cull;
+            const V3 ref = {D.cull_ref[0], D.cull_ref[1], D.cull_ref[2]};
+            const V3 on = o + dot(ref - o, d) * d;
+            const float ox = (float)on.x, oy = (float)on.y, oz = (float)on.z;
+            const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+            const float e_ray = cull_ray_margin(on);   // this ray's part of the error bound
+            auto exact = [&](int i) {
+                const double* g = D.geom + (size_t)i * 4;
+                double lo, hi;
+                if (sphere_roots(o, d, d_o, g[0], g[1], g[2], g[3] * g[3], lo, hi)) {
+                    const double tt = lo > 0 ? lo : hi;
+                    // ties go to the later sphere, as the reference's min_t == t update does
+                    if (tt > 0 && tt <= best) { best = tt; sid = i; }
                 }
-                for (int i = cn + tid; i < ((cn + 7) & ~7); i += BLOCK) cull_blank(s_cull[i >> 1], i & 1);
-                __syncthreads();
-            }
-            if (!SMALL && active) {
-                // float32 screening, two spheres per step; the float64 test only for the pairs
-                // it cannot rule out (in sphere order: ties go to the later sphere)
-                // the screening looks at the ray's whole line, so any point of the line can stand in
-                // for the origin: the one nearest to the middle of the spheres keeps the float32
-                // coordinates (and with them the error bound) small for rays that start far away
-                const V3 ref = {D.cull_ref[0], D.cull_ref[1], D.cull_ref[2]};
-                const V3 on = o + dot(ref - o, d) * d;
-                const float ox = (float)on.x, oy = (float)on.y, oz = (float)on.z;
-                const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
-                const float q_ray = cull_ray_margin(on);   // this ray's part of the error bound
-                auto exact = [&](int i) {
-                    double lo, hi;
-                    if (sphere_roots(o, d, d_o, s_sph[i][0], s_sph[i][1], s_sph[i][2], s_sph[i][3], lo, hi)) {
-                        const double tt = lo > 0 ? lo : hi;
-                        if (tt > 0 && tt <= best) { best = tt; sid = c0 + i; }
-                    }
-                };
-                // The survivors of a lane go to its own short list first and are tested together
-                // afterwards: lanes survive at different spheres, testing on the spot would run the
-                // float64 code once per sphere that any lane of the wave keeps.
-                uint16_t* mine = s_cand[wave][lane];
-                int n_mine = 0;
-                auto flush = [&]() {
-                    for (int k = 0; __ballot(k < n_mine) != 0; ++k)   // the longest list of the active lanes
-                        if (k < n_mine) exact(mine[k]);
-                    n_mine = 0;
-                };
-                // four pairs per step: their table reads are issued together (the table is padded
-                // with blank entries to a multiple of eight spheres)
-                const int np = ((cn + 7) >> 3) << 2;
-                for (int p = 0; p < np; p += 4) {
-                    v2f t[4];
+            };
+            // The survivors of a lane go to its own short list first and are tested together
+            // afterwards, in sphere order: lanes survive at different spheres, testing on the
+            // spot would run the float64 code once per sphere that any lane of the wave keeps.
+            uint16_t* mine = s_cand[wave][lane];
+            int n_mine = 0;
+            auto flush = [&]() {
+                for (int k = 0; __ballot(k < n_mine) != 0; ++k)   // the longest list of the active lanes
+                    if (k < n_mine) exact(mine[k]);
+                n_mine = 0;
+            };
+            const int np = ((S + 7) >> 3) << 2;   // the table is padded with blank entries
+            for (int p = 0; p < np; p += 4) {
+                v2f t[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) t[k] = cull_test(s_cull[p + k], ox, oy, oz, dx, dy, dz, q_ray);
+                for (int k = 0; k < 4; ++k) {
+                    CullPair cp;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (!(t[k].x > 0) && 2 * (p + k) < cn) mine[n_mine++] = (uint16_t)(2 * (p + k));
-                        if (!(t[k].y > 0) && 2 * (p + k) + 1 < cn) mine[n_mine++] = (uint16_t)(2 * (p + k) + 1);
+                    for (int w = 0; w < 2; ++w) {
+                        cp.cx[w] = table[p + k].cx[w]; cp.cy[w] = table[p + k].cy[w]; cp.cz[w] = table[p + k].cz[w];
+                        cp.r[w] = table[p + k].r[w]; cp.e[w] = table[p + k].e[w];
                     }
-                    if (__ballot(n_mine > CAND_MAX - 8) != 0) flush();   // some lane's list is nearly full
+                    t[k] = cull_test(cp, ox, oy, oz, dx, dy, dz, e_ray);
                 }
-                flush();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!(t[k].x > 0) && 2 * (p + k) < S) mine[n_mine++] = (uint16_t)(2 * (p + k));
+                    if (!(t[k].y > 0) && 2 * (p + k) + 1 < S) mine[n_mine++] = (uint16_t)(2 * (p + k) + 1);
+                }
+                if (__ballot(n_mine > CAND_MAX - 8) != 0) flush();   // some lane's list is nearly full
             }
+            flush();
+        }
+        {
+            const int c0 = 0, cn = S;
             if (SMALL && active) {
                 // two spheres per iteration: two independent dependency chains in flight
                 int i = 0;
@@ -649,7 +647,7 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
     // sets (A, B): while a tile is computed, the parent record of the next tile and the parent
     // index of the tile after it are in flight, and no loaded register is copied (a copy
     // would force the wave to wait for the load at once).
-    const int steps = SMALL ? max(0, min(nt, t_first + q) - t_first) : q;
+    const int steps = max(0, min(nt, t_first + q) - t_first);
     Meta mA = meta_of(0);
     uint32_t pA = load_link(mA);
     Meta mB = meta_of(1);
@@ -668,7 +666,7 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
         parA = load_parent(mA2, pA);
         const Meta mB2 = meta_of(step + 3);
         pB = load_link(mB2);
-        if (SMALL ? (step + 1 < steps) : true) process(mB, parB);
+        if (step + 1 < steps) process(mB, parB);
         mA = mA2;
         mB = mB2;
     }
