@@ -2,6 +2,7 @@
 
     python3 tools/config_runs.py spot [MODE]     3840x2160 spotlight scene, 64 samples (soft-shadow heavy)
     python3 tools/config_runs.py many [S]        3840x2160 many-sphere scene (intersection bound), default S = 4096
+    python3 tools/config_runs.py example NAME W H   an example scene at any size (e.g. example_4 7680 4320)
 
 Prints one JSON line: rays, time per frame per kernel kind, Mrays/s, image mean."""
 import json, os, sys, time
@@ -12,7 +13,11 @@ from raytracing_amd.Scenes import synthetic
 
 W, H = 3840, 2160
 kind = sys.argv[1]
-if kind == "spot":
+if kind == "example":
+    from raytracing_amd.Scenes.scenes import build_scene
+    W, H = int(sys.argv[3]), int(sys.argv[4])
+    scene, label = build_scene(sys.argv[2], W, H), f"{sys.argv[2]}:{W}x{H}"
+elif kind == "spot":
     mode = sys.argv[2] if len(sys.argv) > 2 else "linear"
     scene, label = synthetic.spotlight_scene(mode, 64, W, H), f"spot:{mode}:64"
 else:
