@@ -176,6 +176,24 @@ def main():
     barrier()
     elapsed_seq = max_over_ranks(time.perf_counter() - t0)
 
+    # ---- end to end, one frame at a time (single GPU only): everything a raytrace(scene) call does
+    # with a warm context - geometry with the count read-back, generating and packing the disk-light
+    # samples from NumPy's stream state, shading, copying the float64 image to the host
+    end_to_end = None
+    if world == 1:
+        end_to_end = {}
+        for job in jobs:
+            np.random.seed(0)
+            barrier()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(job.stream):
+                job.r.trace_checked()
+                job.r.draw_samples()
+                job.r.shade()
+                img = job.ctx.read_image()
+            end_to_end[job.name] = (time.perf_counter() - t0) * 1e3
+            del img
+
     # ---- bookkeeping ----------------------------------------------------------------------
     stats = [job.stats() for job in jobs]            # global (all-rank) counts per frame
     prof = {}
@@ -250,6 +268,7 @@ def main():
                    "frames": args.frames},
         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
         "setup_s": setup_s,
+        "end_to_end_ms_per_frame": end_to_end,
         "roofline": roofline,
         "rooflines": rooflines,
     }
