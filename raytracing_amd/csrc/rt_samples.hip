@@ -1,0 +1,235 @@
+// Disk-light samples: packing of uploaded or generated stream values (k_pack) and NumPy's legacy
+// MT19937 stream on the device (k_mt_generate, k_mt_jump).
+#pragma once
+#include "rt_math.h"
+
+namespace rt {
+
+// ---------------------------------------------------------------------------------------------
+// Sample packing.  The caller's random stream is laid out as the reference consumes it:
+// the block of (node, light) holds all angle uniforms and then all radius uniforms, each
+// as n_points rows of h values (h = the node's hits, or in-beam hits for a spotlight),
+// and the hit with rank j owns column j (reference objects.py:122, :132-133).  Only the
+// hits on the shading list ever read their columns, so every uploaded piece of the
+// stream, chunk[0..n) = stream[a..a+n), is scattered straight into the packed layout
+// (entry-major within a sample, so k_surface reads it fully coalesced).
+// Source of stream values for k_pack: doubles the caller uploaded ...
+struct UploadedStream {
+    static constexpr bool WHOLE_IMAGE = false;   // positions are in this context's own stream
+    const double* chunk;   // chunk[i] = stream[a + i]
+    __device__ __forceinline__ double operator()(int64_t i) const { return chunk[i]; }
+};
+// ... or raw MT19937 state words made on the device: value i of the piece is built from words
+// 2i and 2i+1 exactly as NumPy's legacy random_sample does (53-bit resolution:
+// (a >> 5) * 2^26 + (b >> 6), over 2^53, a and b tempered outputs).
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+struct GeneratedStream {
+    static constexpr bool WHOLE_IMAGE = true;    // positions are in the whole image's stream when the layout says so
+    const uint32_t* raw;   // raw[2 i], raw[2 i + 1]: untempered words of stream[a + i]
+    __device__ __forceinline__ double operator()(int64_t i) const {
+        const uint32_t hi = mt_temper(raw[2 * i]) >> 5, lo = mt_temper(raw[2 * i + 1]) >> 6;
+        return ((double)hi * 67108864.0 + (double)lo) / 9007199254740992.0;
+    }
+};
+
+template <typename Stream>
+__global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, int64_t n) {
+    const SceneConst& sc = *D.sc;
+    const int64_t b = a + n;
+    const int64_t E = D.pack_E;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (int64_t)gridDim.x * BLOCK) {
+        const uint32_t info = D.info[D.list_ray[e]];
+        const int node = D.list_node[e];
+        for (int l = 0; l < D.n_lights; ++l) {
+            const RtLight& Lt = sc.lights[l];
+            if (Lt.kind == RT_LIGHT_POINT) continue;
+            int64_t h, jj;
+            if (Lt.kind == RT_LIGHT_SPOT) {
+                if (!((info >> (I_BEAM_SHIFT + l)) & 1u)) continue;
+                h = D.node_beam[node * RT_MAX_LIGHTS + l];
+                jj = D.list_j[1 + l][e];
+            } else {
+                h = D.node_hits[node];
+                jj = D.list_j[0][e];
+            }
+            const int N = Lt.n_points;
+            int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
+            if (off < 0) continue;
+            if (Stream::WHOLE_IMAGE && D.sample_global) {
+                // this context holds columns [first column, + h) of a block that is wider in the
+                // whole image's stream
+                const size_t KL = (size_t)D.K * RT_MAX_LIGHTS, at = (size_t)node * RT_MAX_LIGHTS + l;
+                off = D.sample_global[at];
+                h = D.sample_global[KL + at];
+                jj += D.sample_global[2 * KL + at];
+            }
+            if (off + 2 * N * h <= a || off >= b) continue;
+            double* dst = D.packed + 2 * (D.pack_base[l] + e);
+            float* dst32 = D.packed32 ? D.packed32 + 2 * (D.pack_base[l] + e) : nullptr;
+            for (int part = 0; part < 2; ++part) {
+                const int64_t first = off + (int64_t)part * N * h + jj;     // stream position of row 0
+                int64_t s0 = first >= a ? 0 : (a - first + h - 1) / h;
+                for (int64_t s = s0; s < N; ++s) {
+                    const int64_t pos = first + s * h;
+                    if (pos >= b) break;
+                    const double u = chunk(pos - a);
+                    dst[2 * s * E + part] = u;
+                    if (dst32) dst32[2 * s * E + part] = (float)u;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MT19937 state sequence on the device (the generator behind NumPy's legacy global stream,
+// numpy.random.random / RandomState).  x[n + 624] = x[n + 397] ^ twist(x[n], x[n + 1]).
+// One workgroup: lane j of 227 computes x[g + j], g advancing by 227 per step - its own
+// previous result is x[g + j - 227] = the x[n + 397] term, the twist operands are 624 back in
+// an LDS ring and were written at least two steps earlier, so one barrier per two steps is
+// enough (the ring of 2048 keeps writes clear of anything still being read).
+//   ring[2048]  x[n] at slot n & 2047 for the last 2048 indices below *gen_end (in and out)
+//   raw[i]      receives x[raw_first + i] for 0 <= i < raw_n (untempered)
+//   generates until *gen_end >= max(raw_first + raw_n, gen_until)
+//
+// Streams: the word sequence is cut into streams of L = 2^ell words; stream t covers the
+// absolute word indices [t L, (t+1) L] (one word of overlap, a value may be built from the
+// last word of one stream and the first of the next) and has its own ring and counter.
+// Stream 0 starts from the caller's key block, the others from windows k_mt_jump made.
+constexpr int MT_N = 624, MT_M = 397, MT_STEP = MT_N - MT_M, MT_RING = 2048;
+__device__ __forceinline__ uint32_t mt_twist(uint32_t lo, uint32_t hi) {
+    const uint32_t y = (lo & 0x80000000u) | (hi & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+// grid: one workgroup per stream t = t0 + blockIdx.x.
+//   raw[w - raw_origin] receives x[w] for the stream's words below w_end
+//   the stream with index last_stream keeps generating until its counter reaches gen_until
+__global__ __launch_bounds__(256) void k_mt_generate(uint32_t* rings, long long* gen_ends, uint32_t* raw, int t0, int ell,
+                                                     long long raw_origin, long long w_end, int last_stream,
+                                                     long long gen_until) {
+    __shared__ uint32_t ring[MT_RING];
+    const int tid = threadIdx.x;
+    const int t = t0 + blockIdx.x;
+    uint32_t* ring_g = rings + (size_t)t * MT_RING;
+    for (int i = tid; i < MT_RING; i += 256) ring[i] = ring_g[i];
+    const long long g0 = gen_ends[t];
+    const long long raw_first = (long long)t << ell;
+    long long raw_end = ((long long)(t + 1) << ell) + 1;
+    if (raw_end > w_end) raw_end = w_end;
+    if (!raw || raw_end < raw_first) raw_end = raw_first;
+    const long long raw_n = raw_end - raw_first;
+    long long target = raw_n > 0 ? raw_end : g0;
+    if (t == last_stream && gen_until > target) target = gen_until;
+    uint32_t* out = raw ? raw + (raw_first - raw_origin) : nullptr;
+    __syncthreads();
+    // words of the window that exist already
+    for (long long n = raw_first + tid; n < raw_end && n < g0; n += 256) out[n - raw_first] = ring[n & (MT_RING - 1)];
+    // two steps per iteration (all four twist operands were written before the previous
+    // barrier); positions as 32-bit offsets from g0
+    const long long todo = target > g0 ? target - g0 : 0;
+    const int iters = (int)((todo + 2 * MT_STEP - 1) / (2 * MT_STEP));
+    const bool lane_on = tid < MT_STEP;
+    const int base = (int)(g0 & (MT_RING - 1));
+    uint32_t prev = lane_on ? ring[(base + tid - MT_STEP) & (MT_RING - 1)] : 0u;
+    // raw index of this lane's word in step 0, relative to the window (may be negative)
+    long long rel = g0 + tid - raw_first;
+    int slot = (base + tid) & (MT_RING - 1);
+    for (int it = 0; it < iters; ++it) {
+        if (lane_on) {
+            const int s0 = slot, s1 = (slot + MT_STEP) & (MT_RING - 1);
+            const uint32_t lo0 = ring[(s0 - MT_N) & (MT_RING - 1)], hi0 = ring[(s0 - MT_N + 1) & (MT_RING - 1)];
+            const uint32_t lo1 = ring[(s1 - MT_N) & (MT_RING - 1)], hi1 = ring[(s1 - MT_N + 1) & (MT_RING - 1)];
+            const uint32_t x0 = prev ^ mt_twist(lo0, hi0);
+            const uint32_t x1 = x0 ^ mt_twist(lo1, hi1);
+            ring[s0] = x0;
+            ring[s1] = x1;
+            if (rel >= 0 && rel < raw_n) out[rel] = x0;
+            if (rel + MT_STEP >= 0 && rel + MT_STEP < raw_n) out[rel + MT_STEP] = x1;
+            prev = x1;
+        }
+        slot = (slot + 2 * MT_STEP) & (MT_RING - 1);
+        rel += 2 * MT_STEP;
+        __syncthreads();
+    }
+    for (int i = tid; i < MT_RING; i += 256) ring_g[i] = ring[i];
+    if (tid == 0) gen_ends[t] = g0 + (long long)iters * 2 * MT_STEP;
+}
+
+// Jump-ahead.  Workgroup blockIdx.x makes the start window of stream t = blockIdx.x + 1:
+// the window at word index t L - 1, reached from the base window (index L - 1, taken from
+// ring `base_ring` whose counter is base_end) by applying, for every set bit b of t - 1, the
+// polynomial x^(L 2^b) mod phi:  new window word j = XOR over set coefficients i of s[i + j],
+// s the sequence generated from the current window.  The low 31 bits of the new window's
+// first word are not meaningful (nothing reads them: that word belongs to the previous
+// stream).  polys: [n_polys][624] coefficient words, polys[b] = x^(L 2^b) mod phi.
+constexpr int MTJ_RING = 4096, MTJ_CHUNK = 8 * MT_STEP;   // coefficients consumed per round
+__global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen_ends, int base_ring, long long base_end,
+                                                 const uint32_t* polys, int n_polys, int ell) {
+    __shared__ uint32_t xs[MTJ_RING];     // s[i] at slot i & 4095
+    __shared__ uint32_t coef[MT_N];
+    __shared__ uint32_t win[MT_N];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x + 1;
+    const long long L = 1ll << ell;
+    // base window = x[L-1 .. L+622]
+    for (int j = tid; j < MT_N; j += 640) win[j] = rings[(size_t)base_ring * MT_RING + ((L - 1 + j) & (MT_RING - 1))];
+    (void)base_end;
+    __syncthreads();
+    for (int b = 0; b < n_polys; ++b) {
+        if (!(((unsigned)(t - 1) >> b) & 1u)) continue;      // uniform
+        for (int j = tid; j < MT_N; j += 640) {
+            xs[j] = win[j];
+            coef[j] = polys[(size_t)b * MT_N + j];
+        }
+        __syncthreads();
+        uint32_t acc = 0;
+        uint32_t prev = (tid < MT_STEP) ? xs[MT_N - MT_STEP + tid] : 0u;   // own-chain value s[gen - 227 + tid]
+        int gen = MT_N;                                                     // s[0 .. gen) exist
+        for (int c0 = 0; c0 < 19937; c0 += MTJ_CHUNK) {
+            // make s available up to c0 + MTJ_CHUNK + 623
+            while (gen < c0 + MTJ_CHUNK + MT_N) {
+                if (tid < MT_STEP) {
+                    const int n0 = gen + tid, n1 = n0 + MT_STEP;
+                    const uint32_t x0 = prev ^ mt_twist(xs[(n0 - MT_N) & (MTJ_RING - 1)], xs[(n0 - MT_N + 1) & (MTJ_RING - 1)]);
+                    const uint32_t x1 = x0 ^ mt_twist(xs[(n1 - MT_N) & (MTJ_RING - 1)], xs[(n1 - MT_N + 1) & (MTJ_RING - 1)]);
+                    xs[n0 & (MTJ_RING - 1)] = x0;
+                    xs[n1 & (MTJ_RING - 1)] = x1;
+                    prev = x1;
+                }
+                gen += 2 * MT_STEP;
+                __syncthreads();
+            }
+            // accumulate the coefficients c0 .. c0 + MTJ_CHUNK
+            if (tid < MT_N) {
+                const int c1 = min(c0 + MTJ_CHUNK, 19937);
+                for (int w = c0 >> 5; w <= (c1 - 1) >> 5; ++w) {
+                    uint32_t bits = __builtin_amdgcn_readfirstlane(coef[w]);
+                    // keep only coefficients inside [c0, c1)
+                    const int lo = w << 5;
+                    if (lo < c0) bits &= ~0u << (c0 - lo);
+                    if (lo + 32 > c1) bits &= ~0u >> (lo + 32 - c1);
+                    while (bits) {
+                        const int i = lo + __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        acc ^= xs[(i + tid) & (MTJ_RING - 1)];
+                    }
+                }
+            }
+            __syncthreads();   // the next round overwrites ring slots this round read
+        }
+        if (tid < MT_N) win[tid] = acc;
+        __syncthreads();
+    }
+    // the stream's ring: window word j is x[t L - 1 + j]
+    const long long first = (long long)t * L - 1;
+    for (int j = tid; j < MT_N; j += 640) rings[(size_t)t * MT_RING + ((first + j) & (MT_RING - 1))] = win[j];
+    if (tid == 0) gen_ends[t] = first + MT_N;
+}
+
+}  // namespace rt
