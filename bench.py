@@ -139,25 +139,39 @@ def main():
     def max_over_ranks(seconds):
         if world == 1:
             return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+        on_gpu = torch.distributed.get_backend(group) == "nccl"
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
         return float(t.item())
 
     # ---- timed region 1: the metric.  Frames are independent, every frame has its own stream,
     # so the latency-bound deep levels of one frame overlap the others.  No per-kernel events.
     serial = args.frames == "sequential"
-    for _ in range(args.warmup):
-        for job in jobs:
-            job.step()
-            if serial:
+
+    def one_step():
+        if serial:
+            for job in jobs:
+                job.step()
                 job.synchronize()
+        elif world == 1:
+            for job in jobs:
+                job.step()
+        else:
+            # several ranks: issue the frames level by level, so that the per-level exchanges of
+            # the four frames interleave in the process group's queue instead of one frame's
+            # whole chain of exchanges standing in front of the next frame's first one
+            for level in range(jobs[0].n_levels):
+                for job in jobs:
+                    job.step_level(level)
+            for job in jobs:
+                job.step_finish()
+
+    for _ in range(args.warmup):
+        one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        for job in jobs:
-            job.step()
-            if serial:
-                job.synchronize()
+        one_step()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 

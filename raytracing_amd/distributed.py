@@ -48,11 +48,17 @@ class Comm:
     def __init__(self, group=None, device=None):
         self.group = group
         self.device = device          # torch device the backend's tensors must live on
+        self.host_staged = False      # device tensors go through host copies (gloo)
         if group is None:
             self.rank, self.world = 0, 1
         else:
             import torch.distributed as dist
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            if device is not None and dist.get_backend(group) != "nccl":
+                # gloo's handling of device tensors is unreliable here; small exchanges use host
+                # tensors and tiles are copied through the host
+                self.device = None
+                self.host_staged = True
 
     def _t(self, a):
         import torch
@@ -91,6 +97,19 @@ class Comm:
         if self.world == 1:
             return
         import torch.distributed as dist
+        if self.host_staged and (tile.is_cuda or (full is not None and full.is_cuda)):
+            import torch
+            host_full = torch.empty(full.shape, dtype=full.dtype) if self.rank == 0 else None
+            self.host_staged = False
+            try:
+                self.gather_tiles(host_full, tile.cpu(), bounds, width)
+            finally:
+                self.host_staged = True
+            if self.rank == 0:
+                for r in range(1, self.world):
+                    lo, hi = int(bounds[r]) * width, int(bounds[r + 1]) * width
+                    full[lo:hi].copy_(host_full[lo:hi])
+            return
         ops = []
         if self.rank == 0:
             for r in range(1, self.world):
@@ -233,24 +252,26 @@ class ShardedRenderer:
 
     def trace(self):
         """Geometry phase with the per-level exchange of batch sizes."""
-        ctx, comm = self.ctx, self.comm
-        if comm.world == 1:
-            ctx.trace_geometry()
-            return
-        if self.batch_tensor is not None:
-            # batch sizes stay on the GPU: the all-reduce is queued on the kernels' stream
-            # between two levels and nothing waits on the host
-            import torch.distributed as dist
-            ls = self.tree.level_start
-            for level in range(self.tree.n_levels):
-                if level > 0:
-                    dist.all_reduce(self.batch_tensor[int(ls[level]):int(ls[level + 1])], group=comm.group)
-                ctx.trace_level(level)
+        if self.comm.world == 1:
+            self.ctx.trace_geometry()
             return
         for level in range(self.tree.n_levels):
-            if level > 0:
+            self.trace_level(level)
+
+    def trace_level(self, level):
+        """One bounce level: whole-image batch sizes of the level's nodes (sum over the
+        ranks, the small-batch rule needs them), then the level's kernels."""
+        ctx, comm = self.ctx, self.comm
+        if level > 0 and comm.world > 1:
+            if self.batch_tensor is not None:
+                # batch sizes stay on the GPU: the all-reduce is queued on the kernels' stream
+                # between two levels and nothing waits on the host
+                import torch.distributed as dist
+                ls = self.tree.level_start
+                dist.all_reduce(self.batch_tensor[int(ls[level]):int(ls[level + 1])], group=comm.group)
+            else:
                 ctx.set_global_batches(level, comm.all_reduce_sum(ctx.level_batches(level)))
-            ctx.trace_level(level)
+        ctx.trace_level(level)
 
     def trace_checked(self, output_ptr=None):
         """trace() with arena-overflow handling: every rank doubles its arena and
@@ -455,6 +476,23 @@ class FrameJob:
             r.shade()
             if self.comm.world > 1:
                 self.comm.gather_tiles(self.full, self.tile, r.bounds, self.width)
+
+    # The same step in pieces, for callers that interleave several jobs level by level: the
+    # collectives of one process group run in issue order, so with whole steps issued one job
+    # after the other a job's first exchange would queue behind the previous job's last one.
+    @property
+    def n_levels(self):
+        return self.r.tree.n_levels
+
+    def step_level(self, level):
+        with self.torch.cuda.stream(self.stream):
+            self.r.trace_level(level)
+
+    def step_finish(self):
+        with self.torch.cuda.stream(self.stream):
+            self.r.shade()
+            if self.comm.world > 1:
+                self.comm.gather_tiles(self.full, self.tile, self.r.bounds, self.width)
 
     def synchronize(self):
         self.stream.synchronize()
