@@ -190,6 +190,14 @@ def main():
     barrier()
     elapsed_seq = max_over_ranks(time.perf_counter() - t0)
 
+    prof = {}
+    for job in jobs:
+        for kind, rec in job.profile(reset=False).items():
+            acc = prof.setdefault(kind, {"ms": 0.0, "launches": 0})
+            acc["ms"] += rec["ms"]
+            acc["launches"] += rec["launches"]
+        job.profile_enable(False)
+
     # ---- end to end, one frame at a time (single GPU only): everything a raytrace(scene) call does
     # with a warm context - geometry with the count read-back, generating and packing the disk-light
     # samples from NumPy's stream state, shading, copying the float64 image to the host
@@ -210,12 +218,6 @@ def main():
 
     # ---- bookkeeping ----------------------------------------------------------------------
     stats = [job.stats() for job in jobs]            # global (all-rank) counts per frame
-    prof = {}
-    for job in jobs:
-        for kind, rec in job.profile(reset=False).items():
-            acc = prof.setdefault(kind, {"ms": 0.0, "launches": 0})
-            acc["ms"] += rec["ms"]
-            acc["launches"] += rec["launches"]
     if rank != 0:
         for job in jobs:
             job.close()

@@ -59,8 +59,11 @@ __device__ __forceinline__ double xdiv(double a, double b) {
 // divisions, the way numpy.linalg.norm + array division round.
 __device__ __forceinline__ V3 normalize(V3 v) {
     const double len = xsqrt(dot(v, v));
-    const bool fast = mid_range(len) && (mid_range(v.x) || v.x == 0) && (mid_range(v.y) || v.y == 0) &&
-                      (mid_range(v.z) || v.z == 0);
+    // fast path: the norm and all three components in the middle of the exponent range (a
+    // component that is exactly zero takes the general path too, which is merely slower)
+    const uint32_t ex = (uint32_t)__double2hiint(v.x) & 0x7fffffffu, ey = (uint32_t)__double2hiint(v.y) & 0x7fffffffu,
+                   ez = (uint32_t)__double2hiint(v.z) & 0x7fffffffu;
+    const bool fast = mid_range(len) && min(min(ex, ey), ez) >= (623u << 20);   // components <= norm < 2^400
     if (__builtin_expect(!fast, 0)) return {v.x / len, v.y / len, v.z / len};
     const double r = refined_rcp(len);
     return {quotient(v.x, len, r), quotient(v.y, len, r), quotient(v.z, len, r)};
