@@ -101,3 +101,38 @@ def test_flatten_rejects_oversized_scenes():
     scene.light_sources = [objects.PointSource()] * 9
     with pytest.raises(ValueError):
         flatten_scene(scene)
+
+
+def test_reference_style_scene_file_loads_unchanged(tmp_path):
+    """A scene module written the way the reference writes them (top-level imports of objects,
+    materials, constants, Scenes.Scene; result in `scene`) runs against this package's classes."""
+    import sys
+    from raytracing_amd.flatten import flatten_scene
+    from raytracing_amd.Scenes.loader import load_scene_file
+    from raytracing_amd.Scenes.scenes import build_scene
+    text = (
+        "import objects\n"
+        "import materials\n"
+        "from constants import *\n"
+        "import Scenes.Scene as Scene\n"
+        "ground = objects.Sphere(x=0, y=0, z=-1000000, radius=1000000,\n"
+        "                        material=materials.Material(diffuse_color=WHITE, reflection_coefficient=0, smoothness=1))\n"
+        "blue = objects.Sphere(x=4, y=0, z=1, radius=1,\n"
+        "                      material=materials.Material(diffuse_color=BLUE, reflection_coefficient=0.1, shininess=10))\n"
+        "yellow = objects.Sphere(y=2, z=1.25, radius=0.5,\n"
+        "                        material=materials.Material(diffuse_color=YELLOW, reflection_coefficient=0.5))\n"
+        "camera = objects.Camera(x=0, y=1, z=4)\n"
+        "scene = Scene.Scene([ground, blue, yellow], [objects.PointSource(x=4, y=0, z=5)], camera, camera.screen,\n"
+        "                    objects.AmbientLight(intensity=1/10, color=WHITE))\n")
+    path = tmp_path / "my_scene.py"
+    path.write_text(text)
+    before = {k: sys.modules.get(k) for k in ("objects", "materials", "constants", "Scenes")}
+    got = flatten_scene(load_scene_file(path, 96, 54))
+    assert {k: sys.modules.get(k) for k in before} == before          # module table restored
+    want = flatten_scene(build_scene("example_1", 96, 54))
+    assert got.pixels_x == 96 and got.pixels_y == 54
+    assert np.array_equal(got.sphere_geom, want.sphere_geom) and np.array_equal(got.sphere_mat, want.sphere_mat)
+    assert np.array_equal(got.screen_position, want.screen_position) and np.array_equal(got.screen_x, want.screen_x)
+    with pytest.raises(ValueError):
+        (tmp_path / "empty.py").write_text("x = 1\n")
+        load_scene_file(tmp_path / "empty.py")
