@@ -276,12 +276,14 @@ def main():
         "ms_per_step": ms_per_step, "ms_per_step_frames_sequential": elapsed_seq / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64 geometry + f32 disk-light samples (f64 re-check)" if mixed else "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{'+'.join(args.scenes)} at {W}x{H}, depths (3,5), example_4 with 30 disk samples/hit "
                                f"(seed 0); one step = all frames, geometry + shading",
                    "rays_per_step": rays, "hits_per_step": hits, "shadow_rays_per_step": shadow_rays,
                    "rows_split": "contiguous cost-balanced row blocks" if world > 1 else "none",
-                   "frames": args.frames},
+                   "frames": args.frames,
+                   "precision": ("f64 everywhere except the disk-light samples of example_4: f32 with certified "
+                                 "shadow decisions, f64 re-evaluation of uncertified hits") if mixed else "f64 everywhere"},
         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
         "setup_s": setup_s,
         "end_to_end_ms_per_frame": end_to_end,
