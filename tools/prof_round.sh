@@ -9,6 +9,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_
 echo kt_seq done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_ovl -o kt -- python3 bench.py --steps 3 --no-cpu-baseline > $O/bench_ovl_rocprof.json 2> $O/kt_ovl.err
 echo kt_ovl done
+[ -x tools/pmc_calib ] || hipcc -O3 --offload-arch=gfx950 tools/pmc_calib.hip -o tools/pmc_calib
 timeout -s KILL 60 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -o c -- tools/pmc_calib > $O/cal_fetch.log 2>&1
 timeout -s KILL 60 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cal_write -o c -- tools/pmc_calib > $O/cal_write.log 2>&1
 echo calib done
