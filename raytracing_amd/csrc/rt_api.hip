@@ -120,6 +120,7 @@ struct RtContext {
     DevBuf<double> X, Y, packed, staging, image;
     DevBuf<float> packed32;
     bool have_packed32 = false;
+    bool simple_shading = false;   // see disk_light_mixed: coefficients in [0, 1], lights with one colour
     int64_t pack_base[RT_MAX_LIGHTS] = {0};
     int64_t pack_E = 0;
     DevBuf<int64_t> sample_off, sample_global;
@@ -419,6 +420,17 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     HIP_TRY(ctx->flags.ensure(4));
     HIP_TRY(ctx->work.ensure(8));
     HIP_TRY(ctx->sample_off.ensure(K * RT_MAX_LIGHTS));
+
+    bool simple = true;
+    for (size_t i = 0; i < S && simple; ++i)
+        for (int c = 3; c < 9; ++c) {
+            const double k = scene->sphere_mat[i * RT_MAT_WIDTH + c];
+            if (!(k >= 0.0 && k <= 1.0)) simple = false;
+        }
+    for (int l = 0; l < scene->n_lights && simple; ++l)
+        if (scene->lights[l].kind != RT_LIGHT_POINT && memcmp(scene->lights[l].diffuse_color, scene->lights[l].specular_color, 24) != 0)
+            simple = false;
+    ctx->simple_shading = simple;
 
     ctx->tree = std::move(tree);
     ctx->sc_host = sc;
@@ -734,7 +746,8 @@ int rt_shade(RtContext* ctx) {
     const bool lds = ctx->S <= SHADE_LDS_SPHERES;
     const bool mixed = ctx->precision == RT_PRECISION_MIXED && ctx->sampled_lights && ctx->S <= SREG && ctx->have_packed32;
     ctx->begin(RT_K_SURFACE);
-    if (lds && mixed) hipLaunchKernelGGL((k_surface<true, true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    if (lds && mixed && ctx->simple_shading) hipLaunchKernelGGL((k_surface<true, true, true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    else if (lds && mixed) hipLaunchKernelGGL((k_surface<true, true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
     else if (lds) hipLaunchKernelGGL((k_surface<true, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
     else hipLaunchKernelGGL((k_surface<false, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
     if (mixed) hipLaunchKernelGGL((k_surface_redo<true>), dim3(64), dim3(BLOCK), 0, ctx->stream, D);

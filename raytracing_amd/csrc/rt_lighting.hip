@@ -213,7 +213,11 @@ struct F3x2 {
 };
 __device__ __forceinline__ v2f vdot(F3 a, F3x2 b) { return vfma(b.z, a.z, vfma(b.y, a.y, b.x * a.x)); }
 
-template <bool LDS>
+// SIMPLE: every diffuse / specular coefficient of the scene lies in [0, 1] and every disk light
+// has equal diffuse and specular colours (the host checks).  Then clip(nl * k) = k * clip(nl) and
+// clip(p * k) = k * min(p, 1), so one sum of clip(nl) and one of min(p, 1) replace six channel
+// sums, and the specular intensity sum equals the diffuse one.
+template <bool LDS, bool SIMPLE>
 __device__ void disk_light_mixed(const Dev& D, const ShadowSphere* s_sh, const RtLight& Lt, const float* pk,
                                  int64_t stride, V3 Pb, V3 d, V3 n, V3 kdiff, V3 kspec,
                                  double shin, V3& sumId, V3& sumIs, V3& sumKd, V3& sumKs, unsigned& n_unsure) {
@@ -325,29 +329,48 @@ __device__ void disk_light_mixed(const Dev& D, const ShadowSphere* s_sh, const R
                 p = (v2f){__builtin_amdgcn_exp2f(shf * __builtin_amdgcn_logf(fabsf(rdv.x))),
                           __builtin_amdgcn_exp2f(shf * __builtin_amdgcn_logf(fabsf(rdv.y)))};
             F3x2 cId = {vclip01(fall * dcol.x * mult.x), vclip01(fall * dcol.y * mult.y), vclip01(fall * dcol.z * mult.z)};
-            F3x2 cIs = {vclip01(fall * scol.x * mult.x), vclip01(fall * scol.y * mult.y), vclip01(fall * scol.z * mult.z)};
-            F3x2 cKd = {vclip01(nl * kdf.x), vclip01(nl * kdf.y), vclip01(nl * kdf.z)};
-            F3x2 cKs = {vclip01(p * ksf.x), vclip01(p * ksf.y), vclip01(p * ksf.z)};
-            if (!both) {
-                const v2f first = {1.0f, 0.0f};
-                cId.x *= first; cId.y *= first; cId.z *= first; cIs.x *= first; cIs.y *= first; cIs.z *= first;
-                cKd.x *= first; cKd.y *= first; cKd.z *= first; cKs.x *= first; cKs.y *= first; cKs.z *= first;
+            if constexpr (SIMPLE) {
+                v2f cN = vclip01(nl), cP = {fminf(p.x, 1.0f), fminf(p.y, 1.0f)};
+                if (!both) {
+                    const v2f first = {1.0f, 0.0f};
+                    cId.x *= first; cId.y *= first; cId.z *= first; cN *= first; cP *= first;
+                }
+                aId.x += cId.x; aId.y += cId.y; aId.z += cId.z;
+                aKd.x += cN;    // sum of clip(n.l); the coefficients are applied after the loop
+                aKs.x += cP;    // sum of min(|r.d|^shininess, 1)
+            } else {
+                F3x2 cIs = {vclip01(fall * scol.x * mult.x), vclip01(fall * scol.y * mult.y), vclip01(fall * scol.z * mult.z)};
+                F3x2 cKd = {vclip01(nl * kdf.x), vclip01(nl * kdf.y), vclip01(nl * kdf.z)};
+                F3x2 cKs = {vclip01(p * ksf.x), vclip01(p * ksf.y), vclip01(p * ksf.z)};
+                if (!both) {
+                    const v2f first = {1.0f, 0.0f};
+                    cId.x *= first; cId.y *= first; cId.z *= first; cIs.x *= first; cIs.y *= first; cIs.z *= first;
+                    cKd.x *= first; cKd.y *= first; cKd.z *= first; cKs.x *= first; cKs.y *= first; cKs.z *= first;
+                }
+                aId.x += cId.x; aId.y += cId.y; aId.z += cId.z;
+                aIs.x += cIs.x; aIs.y += cIs.y; aIs.z += cIs.z;
+                aKd.x += cKd.x; aKd.y += cKd.y; aKd.z += cKd.z;
+                aKs.x += cKs.x; aKs.y += cKs.y; aKs.z += cKs.z;
             }
-            aId.x += cId.x; aId.y += cId.y; aId.z += cId.z;
-            aIs.x += cIs.x; aIs.y += cIs.y; aIs.z += cIs.z;
-            aKd.x += cKd.x; aKd.y += cKd.y; aKd.z += cKd.z;
-            aKs.x += cKs.x; aKs.y += cKs.y; aKs.z += cKs.z;
             __builtin_amdgcn_sched_barrier(0);   // one pair at a time: interleaving pairs costs registers
         }
     }
     auto total = [](F3x2 v) -> V3 { return {(double)(v.x.x + v.x.y), (double)(v.y.x + v.y.y), (double)(v.z.x + v.z.y)}; };
-    sumId = total(aId); sumIs = total(aIs); sumKd = total(aKd); sumKs = total(aKs);
+    sumId = total(aId);
+    if constexpr (SIMPLE) {
+        const float sN = aKd.x.x + aKd.x.y, sP = aKs.x.x + aKs.x.y;
+        sumIs = sumId;
+        sumKd = {(double)(sN * kdf.x), (double)(sN * kdf.y), (double)(sN * kdf.z)};
+        sumKs = {(double)(sP * ksf.x), (double)(sP * ksf.y), (double)(sP * ksf.z)};
+    } else {
+        sumIs = total(aIs); sumKd = total(aKd); sumKs = total(aKs);
+    }
 }
 
 // Surface colour of one hit under all lights (reference raytrace.py:136-152,
 // :215-234 and objects.py:94-235).  entry: index of the hit in the shading list,
 // which is also the index of its disk-light samples in the packed sample buffer.
-template <bool LDS, bool MIXED>
+template <bool LDS, bool MIXED, bool SIMPLE = false>
 __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphere* s_sh, uint16_t* cand, int64_t entry, uint32_t info,
                             V3 Pb, V3 d, V3 n, const SurfaceMaterial& mat, unsigned& n_samples, unsigned& n_fallback) {
     const V3 kdiff = ld3(mat.kdiff), kspec = ld3(mat.kspec);
@@ -390,7 +413,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
         const int64_t stride = 2 * D.pack_E;
         V3 sumId = {0, 0, 0}, sumIs = {0, 0, 0}, sumKd = {0, 0, 0}, sumKs = {0, 0, 0};
         if constexpr (MIXED) {   // the host launches this variant only when S <= SREG
-            disk_light_mixed<LDS>(D, s_sh, Lt, D.packed32 + 2 * (D.pack_base[l] + entry), stride, Pb, d, n, kdiff, kspec, shin, sumId, sumIs, sumKd, sumKs,
+            disk_light_mixed<LDS, SIMPLE>(D, s_sh, Lt, D.packed32 + 2 * (D.pack_base[l] + entry), stride, Pb, d, n, kdiff, kspec, shin, sumId, sumIs, sumKd, sumKs,
                                   n_fallback);
         } else {
             for (int s = 0; s < N; ++s) {
@@ -413,7 +436,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
 
 // ---------------------------------------------------------------------------------------------
 // Lighting for the dense list of hits whose surface colour matters (all levels).
-template <bool LDS, bool MIXED>
+template <bool LDS, bool MIXED, bool SIMPLE = false>
 __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(Dev D) {
     constexpr int TABLE = MIXED ? SREG : (LDS ? SHADE_LDS_SPHERES : 1);   // the float32 pass is for S <= SREG
     __shared__ ShadowSphere s_sh[TABLE];
@@ -456,7 +479,7 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
         const SurfaceMaterial mat = LDS ? s_mat[sid] : surface_material(D.mat + (size_t)sid * RT_MAT_WIDTH);
         const Surface sf = surface_at(P, centre, info & I_INSIDE, eps);
         unsigned unsure = 0;
-        V3 surf = surface_color<LDS, MIXED>(D, sc, s_sh, LDS ? nullptr : s_cand[tid], e, info, sf.Pb, d, sf.n, mat, my_samples, unsure);
+        V3 surf = surface_color<LDS, MIXED, SIMPLE>(D, sc, s_sh, LDS ? nullptr : s_cand[tid], e, info, sf.Pb, d, sf.n, mat, my_samples, unsure);
         my_hits += 1;
         D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
         if (MIXED && unsure) {

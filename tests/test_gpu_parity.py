@@ -442,3 +442,23 @@ def test_screening_keeps_every_hit(n_spheres, shift):
     # term amplifies: the images then agree to 1e-6 instead of 1e-8 (a dropped pair would change
     # the counts above and whole pixels)
     assert np.abs(got - want.reshape(-1, 3)).max() <= (1e-8 if not any(shift) else 1e-6)
+
+
+@pytest.mark.gpu
+def test_float32_samples_general_coefficients():
+    """Lights whose diffuse and specular colours differ (or coefficients outside [0, 1]) take the
+    float32 sample loop with per-channel sums; it must agree with the float64 evaluation too."""
+    from raytracing_amd.flatten import flatten_scene
+    flat = flatten_scene(build_scene("example_4", 96, 54))
+    flat.lights[0].specular_color = np.array([0.9, 0.7, 1.0])
+    flat.sphere_mat = flat.sphere_mat.copy()
+    flat.sphere_mat[1, 6:9] = [1.4, 0.2, 0.9]          # a specular coefficient above one
+    want, _ = O.render(flat, seed=3)
+    imgs = {}
+    for precision in ("f64", "mixed"):
+        np.random.seed(3)
+        with Renderer(flat, precision=precision) as r:
+            r.begin_rows(0, 54)
+            imgs[precision] = r.render_pixels()
+    assert np.abs(imgs["f64"] - want.reshape(-1, 3)).max() <= 1e-8
+    assert np.abs(imgs["mixed"] - imgs["f64"]).max() <= 2e-5
