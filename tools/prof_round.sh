@@ -3,7 +3,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r1c
+O=$GRAFT_REPO_ROOT/gpurun_out/r1d
 rm -rf $O; mkdir -p $O
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_seq -o kt -- python3 bench.py --steps 3 --no-cpu-baseline --frames sequential > $O/bench_seq_rocprof.json 2> $O/kt_seq.err
 echo kt_seq done
