@@ -230,7 +230,7 @@ def main():
     value = rays / (elapsed / args.steps) / 1e6
 
     # ---- rooflines (rank 0's share of the work, its own kernel times) -------------------------
-    # Algorithmic work per step from the device counters (DESIGN.md section 5):
+    # Algorithmic work per step from the device counters:
     #   k_trace   reads link (4 B) + parent info, hit point, direction (52 B) per non-primary ray,
     #             writes info (4 B) per ray, 48 B per stored hit record, 16 B per live hit and the
     #             per-tile counters (52 B per 64 rays);   FLOPs 22 per (ray, sphere) + 100 per hit

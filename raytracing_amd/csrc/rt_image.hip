@@ -7,8 +7,8 @@ namespace rt {
 // ---------------------------------------------------------------------------------------------
 // Bottom-up colour combination for one level (reference raytrace.py:155-170); the
 // deepest level runs first.  A ray's colour replaces its surface colour in place.
-// Two tiles per loop iteration; per iteration the loads come in two rounds (the info words
-// and counters, then everything the info words select), each round issued together.
+// Two tiles per loop iteration; per iteration the loads come in two sets (the info words
+// and counters, then everything the info words select), each set issued together.
 constexpr int COMBINE_TILES = 2;
 struct CombineSphere {
     double tr, kr, kg, kb;   // transparency, -attenuation * absorption colour
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
         int kn[COMBINE_TILES], first[COMBINE_TILES];
         uint32_t info[COMBINE_TILES];
         unsigned trun[COMBINE_TILES];
-        // round 1: info words and the running child counts of the tiles
+        // first set of loads: info words and the running child counts of the tiles
 #pragma unroll
         for (int u = 0; u < COMBINE_TILES; ++u) {
             const int t = t0 + u;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
                 if (has_children && lane < 3) trun[u] = D.tile_run[(size_t)(tbase + t) * NCNT + lane];
             }
         }
-        // round 2: what the info words select
+        // second set of loads: what the info words select
         double A[COMBINE_TILES], through[COMBINE_TILES];
         V3 surf[COMBINE_TILES], refr[COMBINE_TILES], refl[COMBINE_TILES];
 #pragma unroll

@@ -16,8 +16,7 @@ constexpr int NCNT = RT_NUM_COUNTERS; // per-tile counters: 3 child kinds, hits,
 constexpr int MAX_LEVELS = 32;
 constexpr int MAX_LEVEL_NODES = 1024; // widest level of the static ray tree we accept
 constexpr int MAX_NODES = 65536;
-constexpr int SPH_CHUNK_LARGE = 256;  // spheres staged in LDS per pass of the nearest-hit loop
-constexpr int SPH_CHUNK_SMALL = 64;   // ... for scenes with few spheres (less LDS, more resident workgroups)
+constexpr int SPH_CHUNK_SMALL = 64;   // up to this many spheres the kernels keep all sphere constants in LDS
 constexpr int SHADE_LDS_SPHERES = 128; // sphere and material tables of the lighting kernels kept in LDS up to this many
 
 // counters

@@ -131,7 +131,7 @@ def test_row_strips_through_get_pixel_color(golden_dir):
 @pytest.mark.parametrize("name,size", [("example_1", (333, 187)), ("example_2", (257, 129)),
                                         ("example_3", (500, 500)), ("example_4", (200, 113))])
 def test_against_oracle_at_ragged_sizes(name, size):
-    """Image sizes that are not multiples of the 256-ray tile."""
+    """Image sizes that are not multiples of the 64-ray tile."""
     w, h = size
     scene = build_scene(name, w, h)
     img, tree, batch, hits, beam, cnt = _render(scene, seed=3)
