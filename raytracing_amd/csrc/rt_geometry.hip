@@ -279,32 +279,24 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
             }
             flush();
         }
-        {
-            const int c0 = 0, cn = S;
-            if (SMALL && active) {
-                // two spheres per iteration: two independent dependency chains in flight
-                int i = 0;
-                for (; i + 1 < cn; i += 2) {
-                    double lo0, hi0, lo1, hi1;
-                    const bool h0 = sphere_roots(o, d, d_o, s_sph[i][0], s_sph[i][1], s_sph[i][2], s_sph[i][3], lo0, hi0);
-                    const bool h1 = sphere_roots(o, d, d_o, s_sph[i + 1][0], s_sph[i + 1][1], s_sph[i + 1][2], s_sph[i + 1][3], lo1, hi1);
-                    // ties go to the later sphere, as the reference's min_t == t update does
-                    if (h0) {
-                        const double tt = lo0 > 0 ? lo0 : hi0;
-                        if (tt > 0 && tt <= best) { best = tt; sid = c0 + i; }
-                    }
-                    if (h1) {
-                        const double tt = lo1 > 0 ? lo1 : hi1;
-                        if (tt > 0 && tt <= best) { best = tt; sid = c0 + i + 1; }
-                    }
-                }
-                if (i < cn) {
-                    double lo, hi;
-                    if (sphere_roots(o, d, d_o, s_sph[i][0], s_sph[i][1], s_sph[i][2], s_sph[i][3], lo, hi)) {
-                        const double tt = lo > 0 ? lo : hi;
-                        if (tt > 0 && tt <= best) { best = tt; sid = c0 + i; }
-                    }
-                }
+        if (SMALL && active) {
+            // few spheres, all in LDS: the float64 test for every one, two per iteration (two
+            // independent dependency chains in flight); ties go to the later sphere, as the
+            // reference's min_t == t update does
+            auto test = [&](int i) {
+                double lo, hi;
+                const bool h = sphere_roots(o, d, d_o, s_sph[i][0], s_sph[i][1], s_sph[i][2], s_sph[i][3], lo, hi);
+                return h ? (lo > 0 ? lo : hi) : -1.0;
+            };
+            int i = 0;
+            for (; i + 1 < S; i += 2) {
+                const double t0 = test(i), t1 = test(i + 1);
+                if (t0 > 0 && t0 <= best) { best = t0; sid = i; }
+                if (t1 > 0 && t1 <= best) { best = t1; sid = i + 1; }
+            }
+            if (i < S) {
+                const double t0 = test(i);
+                if (t0 > 0 && t0 <= best) { best = t0; sid = i; }
             }
         }
         if (!tile_ok) return;
