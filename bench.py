@@ -16,16 +16,20 @@ whole-image batch is >= 3), summed over the four frames and all GPUs.
 
 Two timed regions of K steps each, both bracketed by barrier + synchronize:
 1. the metric: the four frames are independent, each runs on its own HIP
-   stream, so their latency-bound deep levels overlap (`value`, `ms_per_step`);
+   stream, so their latency-bound deep levels overlap; the step is issued as a
+   HIP graph (one GPU: one graph per step; several GPUs: one graph per bounce
+   level, the collectives between them) (`value`, `ms_per_step`);
 2. the same steps with the frames one after the other and HIP events around
    every kernel launch on the kernel's stream: per-kernel durations without
    overlap, from which `kernel_ms_per_step` and the rooflines are computed
    (`ms_per_step_frames_sequential` is this region's wall time per step).
 
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every
-frame is split into N contiguous row blocks of equal estimated cost; ranks
-exchange per-node batch sizes after every bounce level (the small-batch rule
-needs whole-image sizes) and the image tiles are gathered on rank 0.
+frame is split into N contiguous row blocks of equal estimated cost; after
+every bounce level one all-reduce sums the per-node batch sizes of all four
+frames (the small-batch rule needs whole-image sizes); the float64 image tiles
+of a step are gathered on rank 0 while the next step is computed (two output
+buffers), all of them before the timed region ends.
 
 Prints ONE JSON line on rank 0.
 """
@@ -110,7 +114,7 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
     import torch
-    from raytracing_amd.distributed import FrameJob, init_group
+    from raytracing_amd.distributed import FrameSet, init_group
 
     rank, world, group = init_group(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -121,17 +125,13 @@ def main():
 
     # ---- set-up: geometry once, then draw + upload the disk-light samples -------------------
     t_setup = time.perf_counter()
-    jobs = []
-    for name in args.scenes:
-        job = FrameJob(name, W, H, device=local_rank, rank=rank, world=world, group=group, precision=args.precision)
-        np.random.seed(0)
-        job.prepare()            # first geometry pass, row split, samples resident in HBM
-        jobs.append(job)
+    frames = FrameSet(args.scenes, W, H, device=local_rank, rank=rank, world=world, group=group, precision=args.precision)
+    frames.prepare(seed=0)       # row split, first geometry pass, samples resident in HBM, graphs captured
+    jobs = frames.jobs
     setup_s = time.perf_counter() - t_setup
 
     def barrier():
-        for job in jobs:
-            job.synchronize()
+        frames.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier(group=group)
@@ -153,18 +153,8 @@ def main():
             for job in jobs:
                 job.step()
                 job.synchronize()
-        elif world == 1:
-            for job in jobs:
-                job.step()
         else:
-            # several ranks: issue the frames level by level, so that the per-level exchanges of
-            # the four frames interleave in the process group's queue instead of one frame's
-            # whole chain of exchanges standing in front of the next frame's first one
-            for level in range(jobs[0].n_levels):
-                for job in jobs:
-                    job.step_level(level)
-            for job in jobs:
-                job.step_finish()
+            frames.step()
 
     for _ in range(args.warmup):
         one_step()
@@ -219,8 +209,7 @@ def main():
     # ---- bookkeeping ----------------------------------------------------------------------
     stats = [job.stats() for job in jobs]            # global (all-rank) counts per frame
     if rank != 0:
-        for job in jobs:
-            job.close()
+        frames.close()
         return
 
     rays = sum(s["rays"] for s in stats)
@@ -282,6 +271,9 @@ def main():
                    "rays_per_step": rays, "hits_per_step": hits, "shadow_rays_per_step": shadow_rays,
                    "rows_split": "contiguous cost-balanced row blocks" if world > 1 else "none",
                    "frames": args.frames,
+                   "issue": ("frames one after the other, kernel by kernel" if serial else
+                             ("HIP graph" if frames.graphs is not None else "kernel by kernel") +
+                             (", one all-reduce per bounce level, tiles travel during the next step" if frames.pipelined else "")),
                    "precision": ("f64 everywhere except the disk-light samples of example_4: f32 with certified "
                                  "shadow decisions, f64 re-evaluation of uncertified hits") if mixed else "f64 everywhere"},
         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
@@ -292,8 +284,7 @@ def main():
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    for job in jobs:
-        job.close()
+    frames.close()
     print(json.dumps(out))
 
 

@@ -194,6 +194,16 @@ int rt_set_global_batches(RtContext *ctx, int32_t level, const int64_t *n_global
  * context's own array.  Call after rt_set_scene. */
 int rt_set_batch_buffer(RtContext *ctx, int32_t *device_batches);
 
+/* The same for several frames (contexts with the same recursion depths on one
+ * GPU) whose small-batch sums (reference raytrace.py:26-27) are to travel in ONE
+ * collective per level: device_batches is int32[n_slots * n_nodes], laid out
+ * level by level and, inside a level, frame by frame; the sizes of node k (a
+ * node of level l) of the frame in `slot` sit at
+ *   n_slots * level_start[l] + slot * (level_start[l+1] - level_start[l]) + (k - level_start[l]),
+ * so [n_slots * level_start[l], n_slots * level_start[l+1]) holds every frame's
+ * sizes of level l.  n_slots == 1 is rt_set_batch_buffer. */
+int rt_set_batch_buffer_shared(RtContext *ctx, int32_t *device_batches, int32_t slot, int32_t n_slots);
+
 /* Per-node results of the geometry phase (synchronises):
  * batch[k] local rays of node k, hits[k] local hits, beam[k][l] local hits
  * inside spotlight l's beam.  Arrays may be NULL. */

@@ -87,6 +87,7 @@ SIGNATURES = {
     "rt_get_level_batches": (C.c_int, [_P, C.c_int32, _I64P]),
     "rt_set_global_batches": (C.c_int, [_P, C.c_int32, _I64P]),
     "rt_set_batch_buffer": (C.c_int, [_P, _P]),
+    "rt_set_batch_buffer_shared": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "rt_get_node_counts": (C.c_int, [_P, _I64P, _I64P, _I64P]),
     "rt_set_sample_layout": (C.c_int, [_P, _I64P, C.c_int64]),
     "rt_upload_samples": (C.c_int, [_P, C.c_int64, _F64P, C.c_int64]),
@@ -267,9 +268,14 @@ class Context:
         a = np.ascontiguousarray(n_global, dtype=np.int64)
         _check(self.lib.rt_set_global_batches(self._h, int(level), _ptr(a, C.c_int64)))
 
-    def set_batch_buffer(self, device_ptr):
-        """Keep whole-image batch sizes in caller-owned device memory (int32[n_nodes]); None: internal."""
-        _check(self.lib.rt_set_batch_buffer(self._h, _P(device_ptr) if device_ptr else None))
+    def set_batch_buffer(self, device_ptr, slot=0, n_slots=1):
+        """Keep whole-image batch sizes in caller-owned device memory (int32[n_slots * n_nodes],
+        level by level and frame by frame inside a level; this context is frame ``slot``);
+        None: internal."""
+        if device_ptr and n_slots > 1:
+            _check(self.lib.rt_set_batch_buffer_shared(self._h, _P(device_ptr), int(slot), int(n_slots)))
+        else:
+            _check(self.lib.rt_set_batch_buffer(self._h, _P(device_ptr) if device_ptr else None))
 
     def node_counts(self):
         K = self.n_nodes

@@ -133,6 +133,13 @@ struct RtContext {
     DevBuf<long long> mt_end;
     uint8_t* user_image8 = nullptr;
     int32_t* user_batches = nullptr;
+    int batch_slot = 0, batch_slots = 1;
+
+    // first element of a level's whole-image batch sizes (see whole_image_batch in rt_geometry.hip)
+    int32_t* level_batches(int level) {
+        const int a = tree.level_start[level], b = tree.level_start[level + 1];
+        return (user_batches ? user_batches : node_nglobal.p) + a + (batch_slots - 1) * a + batch_slot * (b - a);
+    }
 
     int64_t npix = 0;
     int row0 = 0;
@@ -152,7 +159,7 @@ struct RtContext {
         D.geom = geom.p; D.mat = mat.p; D.fres = fres.p; D.cull = cull.p; D.cull_ref[0] = cull_ref[0]; D.cull_ref[1] = cull_ref[1]; D.cull_ref[2] = cull_ref[2]; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
         D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
-        D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
+        D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.batch_slot = batch_slot; D.batch_slots = batch_slots; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
         D.node_tile0 = node_tile0.p; D.node_ntiles = node_ntiles.p; D.node_start = node_start.p; D.node_pre = node_pre.p;
         D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p; D.wave_off = wave_off.p;
         D.flags = flags.p; D.work = work.p;
@@ -441,6 +448,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     ctx->spot_mask = spot_mask;
     for (auto& b : ctx->list_j) b.release();   // sized per frame for the lights of this scene
     ctx->user_batches = nullptr;
+    ctx->batch_slot = 0; ctx->batch_slots = 1;
     ctx->have_scene = true;
     ctx->frame_begun = ctx->geometry_done = ctx->layout_set = ctx->shaded = false;
     return RT_OK;
@@ -551,8 +559,7 @@ int rt_set_global_batches(RtContext* ctx, int32_t level, const int64_t* n_global
         if (n_global[i] < 0 || n_global[i] > 0x7FFFFFFF) return fail(RT_ERR_INVALID, "batch size out of range");
         tmp[i] = (int32_t)n_global[i];
     }
-    HIP_TRY(hipMemcpyAsync((ctx->user_batches ? ctx->user_batches : ctx->node_nglobal.p) + k0, tmp.data(), nn * 4,
-                           hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->level_batches(level), tmp.data(), nn * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -769,6 +776,17 @@ int rt_set_batch_buffer(RtContext* ctx, int32_t* device_batches) {
     if (int rc = use_device(ctx)) return rc;
     if (!ctx->have_scene) return fail(RT_ERR_STATE, "rt_set_scene has not been called");
     ctx->user_batches = device_batches;
+    ctx->batch_slot = 0; ctx->batch_slots = 1;
+    return RT_OK;
+}
+
+int rt_set_batch_buffer_shared(RtContext* ctx, int32_t* device_batches, int32_t slot, int32_t n_slots) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->have_scene) return fail(RT_ERR_STATE, "rt_set_scene has not been called");
+    if (!device_batches || n_slots < 1 || slot < 0 || slot >= n_slots)
+        return fail(RT_ERR_INVALID, "slot %d of %d frames in a shared batch buffer", slot, n_slots);
+    ctx->user_batches = device_batches;
+    ctx->batch_slot = slot; ctx->batch_slots = n_slots;
     return RT_OK;
 }
 
@@ -850,7 +868,10 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     unsigned long long work[5] = {0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(work, ctx->work.p, sizeof work, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(n.data(), ctx->node_n.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ng.data(), ctx->user_batches ? ctx->user_batches : ctx->node_nglobal.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    for (int l = 0; l < Lv; ++l) {
+        const int a = ctx->tree.level_start[l], b = ctx->tree.level_start[l + 1];
+        HIP_TRY(hipMemcpyAsync(ng.data() + a, ctx->level_batches(l), (size_t)(b - a) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(hipMemcpyAsync(h.data(), ctx->node_hits.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(nt.data(), ctx->lvl_ntiles.p, Lv * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(tb.data(), ctx->lvl_tilebase.p, Lv * 4, hipMemcpyDeviceToHost, ctx->stream));

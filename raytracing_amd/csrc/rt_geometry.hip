@@ -5,12 +5,23 @@
 
 namespace rt {
 
+// Whole-image batch size of node k (a node of `level`).  The sizes of `batch_slots` frames can
+// share one buffer, laid out level by level and, inside a level, frame by frame, so that all
+// frames' sizes of one level are one contiguous range (one sum over the GPUs per level serves
+// every frame).  With one frame the index is k itself.
+__device__ __forceinline__ int32_t& whole_image_batch(const Dev& D, int k, int level) {
+    const int a = D.level_start[level], b = D.level_start[level + 1];
+    return D.node_nglobal[k + (D.batch_slots - 1) * a + D.batch_slot * (b - a)];
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ void k_init(Dev D) {
     const int tid = threadIdx.x;
+    for (int level = 0; level < D.n_levels; ++level)
+        for (int k = D.level_start[level] + tid; k < D.level_start[level + 1]; k += blockDim.x)
+            whole_image_batch(D, k, level) = 0;
     for (int k = tid; k < D.K; k += blockDim.x) {
         D.node_n[k] = 0;
-        D.node_nglobal[k] = 0;
         D.node_hits[k] = 0;
         D.node_tile0[k] = 0;
         D.node_ntiles[k] = 0;
@@ -38,7 +49,7 @@ __global__ void k_init(Dev D) {
             nt = 0;
         }
         D.node_n[0] = nt ? D.npix : 0;
-        D.node_nglobal[0] = D.node_n[0];
+        whole_image_batch(D, 0, 0) = D.node_n[0];
         D.node_ntiles[0] = nt;
         D.lvl_ntiles[0] = nt;
     }
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
             r.tile_end = t0 + D.node_ntiles[k];
             r.n = D.node_n[k];
             r.bits = (D.node_a[k] & 0xff) | ((D.node_b[k] & 0xff) << 8) | ((D.node_branch[k] & 0xff) << 16) |
-                     ((D.node_nglobal[k] < small_num) ? (1 << 24) : 0);   // reference raytrace.py:26-27
+                     ((whole_image_batch(D, k, level) < small_num) ? (1 << 24) : 0);   // reference raytrace.py:26-27
             s_node[i] = r;
         }
         if (SMALL) {
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
             const int child = D.node_child[k * 3 + c];
             if (child >= 0) {
                 D.node_n[child] = (int)tot;
-                D.node_nglobal[child] = (int)tot;
+                whole_image_batch(D, child, level + 1) = (int)tot;
             }
         } else if (c == C_HIT) {
             D.node_hits[k] = (int)tot;
@@ -526,7 +537,7 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
             if (overflow) {
                 // arena too small: drop the deeper levels and tell the host
                 D.node_n[k] = 0;
-                D.node_nglobal[k] = 0;
+                whole_image_batch(D, k, level + 1) = 0;
                 D.node_tile0[k] = 0;
                 D.node_ntiles[k] = 0;
             } else {

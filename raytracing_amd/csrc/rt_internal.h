@@ -70,7 +70,9 @@ struct Dev {
     int32_t n_levels;
     // per-frame node tables
     int32_t* node_n;        // local batch size
-    int32_t* node_nglobal;  // whole-image batch size (== node_n on one GPU)
+    int32_t* node_nglobal;  // whole-image batch sizes (== node_n on one GPU); use whole_image_batch()
+    int32_t batch_slot;     // this frame's place and the number of frames when several frames share a
+    int32_t batch_slots;    // caller's buffer level by level (0 and 1: the buffer holds this frame alone)
     int32_t* node_hits;
     int32_t* node_beam;     // [K][RT_MAX_LIGHTS]
     int32_t* node_tile0;    // first tile of the node, relative to its level

@@ -47,6 +47,7 @@ class Comm:
 
     def __init__(self, group=None, device=None):
         self.group = group
+        self.tile_group = group       # group the tile transfers run on (see separate_tile_group)
         self.device = device          # torch device the backend's tensors must live on
         self.host_staged = False      # device tensors go through host copies (gloo)
         if group is None:
@@ -73,6 +74,33 @@ class Comm:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
 
+    def all_reduce_device(self, t):
+        """In-place sum of a torch tensor over the ranks.  Device tensors with RCCL: queued behind
+        the work of the current stream, nothing waits on the host.  Backends that cannot take
+        device tensors: through a host copy (synchronises the current stream)."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        if t.is_cuda and self.host_staged:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def separate_tile_group(self):
+        """Give the tile transfers a process group (an RCCL communicator and stream) of their
+        own, so that a frame's tiles can travel while the next frame's per-level sums run.
+        Collective: every rank of the group must call it."""
+        if self.world > 1 and self.tile_group is self.group:
+            import torch.distributed as dist
+            ranks = dist.get_process_group_ranks(self.group)
+            self.tile_group = dist.new_group(ranks=ranks, backend=dist.get_backend(self.group))
+            # set the communicator up now, with every rank taking part, not at the first transfer
+            import torch
+            one = torch.zeros(1, dtype=torch.int32, device=self.device if self.device is not None else "cpu")
+            dist.all_reduce(one, group=self.tile_group)
+
     def all_gather(self, a):
         """Stack every rank's array (same shape everywhere) along a new first axis."""
         a = np.asarray(a)
@@ -94,35 +122,39 @@ class Comm:
         """Point-to-point gather of row tiles into ``full`` on rank 0.  ``full`` and
         ``tile`` are torch tensors of shape (rows * width, 3); rank 0's own tile is
         expected to be a view of ``full`` already."""
+        self.gather_tiles_many([(full, tile, bounds, width)])
+
+    def gather_tiles_many(self, frames):
+        """gather_tiles for several frames, ``[(full, tile, bounds, width), ...]``, as one batch
+        of transfers (one group call for all frames and ranks)."""
         if self.world == 1:
             return
+        import torch
         import torch.distributed as dist
-        if self.host_staged and (tile.is_cuda or (full is not None and full.is_cuda)):
-            import torch
-            host_full = torch.empty(full.shape, dtype=full.dtype) if self.rank == 0 else None
-            self.host_staged = False
-            try:
-                self.gather_tiles(host_full, tile.cpu(), bounds, width)
-            finally:
-                self.host_staged = True
+        group = self.tile_group
+        staged = []
+        if self.host_staged and any(t.is_cuda for _, t, _, _ in frames):
+            for full, tile, bounds, width in frames:
+                host_full = torch.empty(full.shape, dtype=full.dtype) if self.rank == 0 else None
+                staged.append((full, host_full))
+            frames = [(hf, tile.cpu(), bounds, width) for (_, tile, bounds, width), (_, hf) in zip(frames, staged)]
+        ops = []
+        for full, tile, bounds, width in frames:
             if self.rank == 0:
                 for r in range(1, self.world):
                     lo, hi = int(bounds[r]) * width, int(bounds[r + 1]) * width
-                    full[lo:hi].copy_(host_full[lo:hi])
-            return
-        ops = []
-        if self.rank == 0:
-            for r in range(1, self.world):
-                lo, hi = int(bounds[r]) * width, int(bounds[r + 1]) * width
-                if hi > lo:
-                    ops.append(dist.P2POp(dist.irecv, full[lo:hi], dist.get_global_rank(self.group, r) if self.group else r,
-                                          group=self.group))
-        elif tile.numel():
-            ops.append(dist.P2POp(dist.isend, tile, dist.get_global_rank(self.group, 0) if self.group else 0,
-                                  group=self.group))
+                    if hi > lo:
+                        ops.append(dist.P2POp(dist.irecv, full[lo:hi], dist.get_global_rank(group, r), group=group))
+            elif tile.numel():
+                ops.append(dist.P2POp(dist.isend, tile, dist.get_global_rank(group, 0), group=group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if staged and self.rank == 0:
+            for (full, host_full), (_, _, bounds, width) in zip(staged, frames):
+                for r in range(1, self.world):
+                    lo, hi = int(bounds[r]) * width, int(bounds[r + 1]) * width
+                    full[lo:hi].copy_(host_full[lo:hi])
 
 
 def init_group(n_gpus):
@@ -187,7 +219,9 @@ class ShardedRenderer:
         self.bounds = None
         self.arena_rays = 0
         self.rays_per_pixel = 24
-        self.batch_tensor = None      # torch int32 tensor on the GPU holding whole-image batch sizes
+        self.batch_tensor = None      # torch int32 tensor on the GPU holding whole-image batch sizes,
+        self.batch_slot = 0           # possibly shared by batch_slots frames (this one is batch_slot):
+        self.batch_slots = 1          # level by level, frame by frame inside a level
         self.global_hits = self.global_beam = self.global_batch = None
         self.local_hits = self.local_beam = self.local_batch = None
         self.samples_total = 0
@@ -233,8 +267,18 @@ class ShardedRenderer:
             self.bounds = split_rows(self.params.height, self.comm.world, rows, cost)
         self.ctx.set_scene(self.flat, self.params, self.tree)
         if self.batch_tensor is not None:
-            self.ctx.set_batch_buffer(self.batch_tensor.data_ptr())
+            self.ctx.set_batch_buffer(self.batch_tensor.data_ptr(), self.batch_slot, self.batch_slots)
         return self.bounds
+
+    def level_batches(self, level, every_frame=False):
+        """View of the device tensor with this frame's (or every sharing frame's) whole-image
+        batch sizes of one level."""
+        a, b = int(self.tree.level_start[level]), int(self.tree.level_start[level + 1])
+        n = self.batch_slots
+        if every_frame:
+            return self.batch_tensor[n * a:n * b]
+        first = n * a + self.batch_slot * (b - a)
+        return self.batch_tensor[first:first + (b - a)]
 
     @property
     def my_rows(self):
@@ -265,10 +309,8 @@ class ShardedRenderer:
         if level > 0 and comm.world > 1:
             if self.batch_tensor is not None:
                 # batch sizes stay on the GPU: the all-reduce is queued on the kernels' stream
-                # between two levels and nothing waits on the host
-                import torch.distributed as dist
-                ls = self.tree.level_start
-                dist.all_reduce(self.batch_tensor[int(ls[level]):int(ls[level + 1])], group=comm.group)
+                # between two levels and (with RCCL) nothing waits on the host
+                comm.all_reduce_device(self.level_batches(level))
             else:
                 ctx.set_global_batches(level, comm.all_reduce_sum(ctx.level_batches(level)))
         ctx.trace_level(level)
@@ -422,32 +464,42 @@ class FrameJob:
     ``step()`` re-renders it with the samples already resident in HBM.  Every job
     owns a HIP stream (kernels, collectives and tile transfers of the frame are
     ordered on it), so the steps of different jobs overlap unless the caller
-    synchronises between them."""
+    synchronises between them.
 
-    def __init__(self, scene_name, width, height, device=0, rank=0, world=1, group=None, precision="mixed"):
+    ``batches=(tensor, slot, n_slots)``: keep the whole-image batch sizes in a device tensor
+    shared with other frames (:class:`FrameSet`).  ``n_buffers=2``: two output tiles (and, on
+    rank 0, two whole frames), so that one can travel while the next step fills the other."""
+
+    def __init__(self, scene_name, width, height, device=0, rank=0, world=1, group=None, precision="mixed",
+                 comm=None, batches=None, n_buffers=1):
         import torch
         from . import _native
         from .Scenes.scenes import build_scene
         self.torch = torch
         self.name = scene_name
         self.device = torch.device("cuda", device)
-        self.comm = Comm(group, self.device if world > 1 else None)
+        self.comm = comm if comm is not None else Comm(group, self.device if world > 1 else None)
         scene = build_scene(scene_name, width, height)
         params = RenderParams(width=width, height=height)
         self.stream = torch.cuda.Stream(self.device)
         self.ctx = _native.Context(device, self.stream.cuda_stream)
         self.precision = precision
         self.r = ShardedRenderer(scene, params, self.comm, self.ctx)
-        # Batch sizes stay on the GPU between levels when the collectives are RCCL's (stream
-        # ordered, no host round trip).  RT_BATCH_EXCHANGE=host|device overrides; gloo moves
-        # device tensors through the host anyway and gets the host-synchronised exchange.
-        import torch.distributed as dist
-        mode = os.environ.get("RT_BATCH_EXCHANGE") or ("device" if world > 1 and dist.get_backend(group) == "nccl" else "host")
-        if world > 1 and mode == "device":
+        if world > 1 and batches is not None:
+            self.r.batch_tensor, self.r.batch_slot, self.r.batch_slots = batches
+        elif world > 1 and batch_exchange_mode(group) == "device":
             with torch.cuda.stream(self.stream):
                 self.r.batch_tensor = torch.zeros(self.r.tree.n_nodes, dtype=torch.int32, device=self.device)
         self.width, self.height = width, height
+        self.n_buffers = n_buffers if world > 1 else 1
+        self.fulls, self.tiles = [], []
         self.full = self.tile = None
+
+    def use_buffer(self, b):
+        """Direct the following shading passes to output buffer ``b``."""
+        if self.tiles:
+            self.full, self.tile = self.fulls[b], self.tiles[b]
+            self.ctx.set_output(self.tile.data_ptr())
 
     def prepare(self):
         torch, r = self.torch, self.r
@@ -456,11 +508,15 @@ class FrameJob:
             r0, r1 = r.my_rows
             W = self.width
             if self.comm.world > 1:
-                if self.comm.rank == 0:
-                    self.full = torch.empty((self.height * W, 3), dtype=torch.float64, device=self.device)
-                    self.tile = self.full[r0 * W:r1 * W]
-                else:
-                    self.tile = torch.empty(((r1 - r0) * W, 3), dtype=torch.float64, device=self.device)
+                for _ in range(self.n_buffers):
+                    if self.comm.rank == 0:
+                        full = torch.empty((self.height * W, 3), dtype=torch.float64, device=self.device)
+                        self.fulls.append(full)
+                        self.tiles.append(full[r0 * W:r1 * W])
+                    else:
+                        self.fulls.append(None)
+                        self.tiles.append(torch.empty(((r1 - r0) * W, 3), dtype=torch.float64, device=self.device))
+                self.full, self.tile = self.fulls[0], self.tiles[0]
             self.ctx.set_precision(self.precision)
             r.trace_checked(self.tile.data_ptr() if self.tile is not None else None)
             r.draw_samples()
@@ -519,3 +575,174 @@ class FrameJob:
 
     def close(self):
         self.ctx.close()
+
+
+def batch_exchange_mode(group):
+    """Where the per-level batch sizes are summed: ``"device"`` (a device tensor, the sum queued
+    on the stream) or ``"host"`` (read back, summed, written again).  RT_BATCH_EXCHANGE overrides
+    the default, which is the device wherever there is a process group."""
+    return os.environ.get("RT_BATCH_EXCHANGE") or ("device" if group is not None else "host")
+
+
+class FrameSet:
+    """The frames of one benchmark step, rendered together on this process group.
+
+    One GPU: the step (every kernel of every frame, each frame on its own stream) is captured
+    once into a HIP graph and replayed, one launch per step.
+
+    Several GPUs: the kernels of one bounce level of all frames are one graph (frames side by
+    side on their streams); between two levels ONE all-reduce sums the whole-image batch sizes
+    of all frames (they share a device tensor laid out level by level).  Shading writes the
+    output tiles alternately into two buffers: the tiles of step k travel to rank 0 on a stream
+    and a process group of their own while step k + 1 is computed; a buffer is reused only
+    after its transfer has finished.
+
+    RT_STEP_GRAPH=0 issues the same work without graphs.  With RT_BATCH_EXCHANGE=host the frames
+    fall back to per-frame host-side exchanges, issued level by level."""
+
+    def __init__(self, scene_names, width, height, device=0, rank=0, world=1, group=None, precision="mixed"):
+        import torch
+        self.torch = torch
+        self.world, self.rank = world, rank
+        self.device = torch.device("cuda", device)
+        self.comm = Comm(group, self.device if world > 1 else None)
+        self.use_graphs = os.environ.get("RT_STEP_GRAPH", "1") != "0"
+        self.pipelined = world > 1 and batch_exchange_mode(group) == "device"
+        self.stream = torch.cuda.Stream(self.device)          # levels are joined here, collectives queue here
+        self.tile_stream = torch.cuda.Stream(self.device)     # tile transfers
+        F = len(scene_names)
+        self.batches = None
+        shared = [None] * F
+        if self.pipelined:
+            from .tree import build_tree
+            p = RenderParams(width=width, height=height)
+            K = build_tree(p.max_reflection_depth, p.max_refraction_depth).n_nodes
+            with torch.cuda.stream(self.stream):
+                self.batches = torch.zeros(F * K, dtype=torch.int32, device=self.device)
+            self.stream.synchronize()
+            shared = [(self.batches, f, F) for f in range(F)]
+            self.comm.separate_tile_group()
+        self.jobs = [FrameJob(name, width, height, device=device, rank=rank, world=world, group=group,
+                              precision=precision, comm=self.comm, batches=shared[f],
+                              n_buffers=2 if self.pipelined else 1)
+                     for f, name in enumerate(scene_names)]
+        self.graphs = None
+        self.steps_issued = 0
+        self.tiles_sent = [None, None]        # event per output buffer: its last transfer has finished
+
+    def prepare(self, seed=0):
+        """Set every frame up (row split, first geometry pass, samples resident in HBM); every
+        frame starts from NumPy's global stream seeded with ``seed``, as separate runs of the
+        reference would."""
+        for job in self.jobs:
+            np.random.seed(seed)
+            job.prepare()
+        self.synchronize()
+        if self.use_graphs and (self.world == 1 or self.pipelined):
+            self.capture()
+
+    # ---- issuing work -------------------------------------------------------------------------
+    def _side_by_side(self, body):
+        """Run ``body(job)`` for every frame on the frame's stream, forked from and joined into
+        the set's stream (also the way the frames enter a graph under capture)."""
+        torch = self.torch
+        fork = torch.cuda.Event()
+        fork.record(self.stream)
+        for job in self.jobs:
+            job.stream.wait_event(fork)
+            body(job)
+            done = torch.cuda.Event()
+            done.record(job.stream)
+            self.stream.wait_event(done)
+
+    def _captured(self, body):
+        torch = self.torch
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self.stream):
+            g.capture_begin(capture_error_mode="thread_local")
+            try:
+                self._side_by_side(body)
+            finally:
+                g.capture_end()
+        return g
+
+    @staticmethod
+    def _level(level):
+        return lambda job: job.ctx.trace_level(level)
+
+    @staticmethod
+    def _shade(buffer):
+        def body(job):
+            job.use_buffer(buffer)
+            job.ctx.shade()
+        return body
+
+    @staticmethod
+    def _whole(job):
+        job.ctx.trace_geometry()
+        job.ctx.shade()
+
+    def capture(self):
+        if self.world == 1:
+            self.graphs = {"step": self._captured(self._whole)}
+        else:
+            self.graphs = {"level": [self._captured(self._level(l)) for l in range(self.jobs[0].n_levels)],
+                           "shade": [self._captured(self._shade(b)) for b in range(2)]}
+        self.synchronize()
+
+    def _run(self, kind, index, body):
+        if self.graphs is not None:
+            g = self.graphs[kind]
+            (g if index is None else g[index]).replay()
+        else:
+            self._side_by_side(body)
+
+    def step(self):
+        torch = self.torch
+        if self.world > 1 and not self.pipelined:
+            for level in range(self.jobs[0].n_levels):
+                for job in self.jobs:
+                    job.step_level(level)
+            for job in self.jobs:
+                job.step_finish()
+            return
+        with torch.cuda.stream(self.stream):
+            if self.world == 1:
+                self._run("step", None, self._whole)
+                return
+            first = self.jobs[0].r
+            for level in range(first.tree.n_levels):
+                if level > 0:
+                    self.comm.all_reduce_device(first.level_batches(level, every_frame=True))
+                self._run("level", level, self._level(level))
+            b = self.steps_issued & 1
+            self.steps_issued += 1
+            if self.tiles_sent[b] is not None:
+                self.stream.wait_event(self.tiles_sent[b])
+            self._run("shade", b, self._shade(b))
+            shaded = torch.cuda.Event()
+            shaded.record(self.stream)
+        with torch.cuda.stream(self.tile_stream):
+            self.tile_stream.wait_event(shaded)
+            self.comm.gather_tiles_many([(j.fulls[b], j.tiles[b], j.r.bounds, j.width) for j in self.jobs])
+            sent = torch.cuda.Event()
+            sent.record(self.tile_stream)
+            self.tiles_sent[b] = sent
+        for job in self.jobs:                      # what image() reads and a later FrameJob.step() fills
+            job.use_buffer(b)
+
+    def synchronize(self):
+        for job in self.jobs:
+            job.synchronize()
+        self.stream.synchronize()
+        self.tile_stream.synchronize()
+
+    def images(self):
+        self.synchronize()
+        return [job.image() for job in self.jobs]
+
+    def close(self):
+        self.synchronize()
+        self.graphs = None
+        for job in self.jobs:
+            job.close()
