@@ -114,10 +114,11 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
                     }
                     col = clip01(((1 - cs.tr) * (1 - A[u])) * surf[u] + (cs.tr * (1 - A[u])) * rf + A[u] * refl[u]);
                 }
-                D.cr[idx] = col.x; D.cg[idx] = col.y; D.cb[idx] = col.z;
-                if (level == 0) {
+                if (level == 0) {   // a primary ray's colour is the pixel; no parent reads it
                     double* out = D.image + (size_t)(first[u] + lane) * 3;
                     out[0] = col.x; out[1] = col.y; out[2] = col.z;
+                } else {
+                    D.cr[idx] = col.x; D.cg[idx] = col.y; D.cb[idx] = col.z;
                 }
             }
         }

@@ -683,11 +683,18 @@ class FrameSet:
         job.ctx.shade()
 
     def capture(self):
-        if self.world == 1:
-            self.graphs = {"step": self._captured(self._whole)}
-        else:
-            self.graphs = {"level": [self._captured(self._level(l)) for l in range(self.jobs[0].n_levels)],
-                           "shade": [self._captured(self._shade(b)) for b in range(2)]}
+        try:
+            if self.world == 1:
+                self.graphs = {"step": self._captured(self._whole)}
+            else:
+                self.graphs = {"level": [self._captured(self._level(l)) for l in range(self.jobs[0].n_levels)],
+                               "shade": [self._captured(self._shade(b)) for b in range(2)]}
+        except RuntimeError as exc:
+            # the same work is then issued kernel by kernel (same order of collectives, so ranks
+            # may differ in this); say so, the timing is affected
+            import sys
+            print(f"[raytracing_amd] HIP graph capture failed, issuing kernels directly: {exc}", file=sys.stderr)
+            self.graphs = None
         self.synchronize()
 
     def _run(self, kind, index, body):
