@@ -4,12 +4,14 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "mt_jump.h"
 #include "rt_kernels.hip"
+#include "hier_build.h"
 
 using namespace rt;
 
@@ -107,6 +109,11 @@ struct RtContext {
     DevBuf<double> geom, mat, fres;
     DevBuf<float> cull;
     double cull_ref[3] = {0, 0, 0};
+    DevBuf<Group8> hier_top, hier_mid, hier_leaf;
+    DevBuf<uint32_t> hier_top_ref;
+    DevBuf<uint16_t> hier_ids;
+    int hier_top_groups = 0;
+    float hier_window = 0, hier_extent = 0;
     DevBuf<SceneConst> sc;
     DevBuf<int32_t> node_a, node_b, node_branch, node_child, level_start;
     DevBuf<int32_t> node_n, node_nglobal, node_hits, node_beam, node_tile0, node_ntiles, lvl_ntiles, lvl_tilebase, flags;
@@ -157,6 +164,7 @@ struct RtContext {
     Dev dev() const {
         Dev D{};
         D.geom = geom.p; D.mat = mat.p; D.fres = fres.p; D.cull = cull.p; D.cull_ref[0] = cull_ref[0]; D.cull_ref[1] = cull_ref[1]; D.cull_ref[2] = cull_ref[2]; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
+        D.hier_top = hier_top.p; D.hier_top_ref = hier_top_ref.p; D.hier_mid = hier_mid.p; D.hier_leaf = hier_leaf.p; D.hier_ids = hier_ids.p; D.hier_top_groups = hier_top_groups; D.hier_window = hier_window; D.hier_extent = hier_extent;
         D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
         D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.batch_slot = batch_slot; D.batch_slots = batch_slots; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
@@ -308,7 +316,7 @@ void rt_destroy(RtContext* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->collect();
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
-    ctx->geom.release(); ctx->mat.release(); ctx->fres.release(); ctx->cull.release(); ctx->sc.release();
+    ctx->geom.release(); ctx->mat.release(); ctx->fres.release(); ctx->cull.release(); ctx->hier_top.release(); ctx->hier_mid.release(); ctx->hier_leaf.release(); ctx->hier_top_ref.release(); ctx->hier_ids.release(); ctx->sc.release();
     ctx->node_a.release(); ctx->node_b.release(); ctx->node_branch.release(); ctx->node_child.release();
     ctx->level_start.release(); ctx->node_n.release(); ctx->node_nglobal.release(); ctx->node_hits.release();
     ctx->node_beam.release(); ctx->node_tile0.release(); ctx->node_ntiles.release(); ctx->lvl_ntiles.release();
@@ -373,6 +381,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     HIP_TRY(ctx->mat.ensure(S * RT_MAT_WIDTH));
     HIP_TRY(ctx->fres.ensure(S * 4));
     HIP_TRY(ctx->sc.ensure(1));
+    ctx->hier_top_groups = 0;
     if (S) {
         HIP_TRY(hipMemcpy(ctx->geom.p, scene->sphere_geom, S * 4 * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->mat.p, scene->sphere_mat, S * RT_MAT_WIDTH * sizeof(double), hipMemcpyHostToDevice));
@@ -408,6 +417,32 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
         }
         HIP_TRY(ctx->cull.ensure(n_pairs * 10));
         HIP_TRY(hipMemcpy(ctx->cull.p, cull.data(), n_pairs * sizeof(CullPair), hipMemcpyHostToDevice));
+        // bounding-sphere hierarchy above that table (RT_HIERARCHY=0: screen every sphere for every ray)
+        ctx->hier_top_groups = 0;
+        const char* use_hier = getenv("RT_HIERARCHY");
+        if (S > SPH_CHUNK_SMALL && !(use_hier && use_hier[0] == '0')) {
+            const HostHierarchy H = build_hierarchy(scene->sphere_geom, S);
+            auto upload = [](auto& buf, const auto& v) -> hipError_t {
+                if (hipError_t e = buf.ensure(std::max<size_t>(1, v.size()))) return e;
+                return v.empty() ? hipSuccess : hipMemcpy(buf.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice);
+            };
+            HIP_TRY(upload(ctx->hier_top, H.top));
+            HIP_TRY(upload(ctx->hier_mid, H.mid));
+            HIP_TRY(upload(ctx->hier_leaf, H.leaf));
+            HIP_TRY(upload(ctx->hier_top_ref, H.top_ref));
+            HIP_TRY(upload(ctx->hier_ids, H.ids));
+            ctx->hier_top_groups = (int)H.top.size();
+            // the windows of k_trace's search: a few sphere radii first; twice the distance from the
+            // tables' reference point to the farthest grouped sphere covers every ray's way through them
+            double reach = 0;
+            for (int b = 0; b < H.blocks; ++b) {
+                const double* q = H.block_bound.data() + (size_t)b * 4;
+                const double dx = q[0] - ctx->cull_ref[0], dy = q[1] - ctx->cull_ref[1], dz = q[2] - ctx->cull_ref[2];
+                reach = std::max(reach, sqrt(dx * dx + dy * dy + dz * dz) + q[3]);
+            }
+            ctx->hier_extent = (float)(2.5 * reach);
+            ctx->hier_window = (float)std::max(4 * H.typical_radius, 2.5 * reach / 256);
+        }
     }
     HIP_TRY(hipMemcpy(ctx->sc.p, &sc, sizeof sc, hipMemcpyHostToDevice));
     HIP_TRY(ctx->node_a.ensure(K)); HIP_TRY(ctx->node_b.ensure(K)); HIP_TRY(ctx->node_branch.ensure(K));

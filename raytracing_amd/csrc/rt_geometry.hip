@@ -73,7 +73,9 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
     __shared__ NodeRec s_node[MAX_LEVEL_NODES];
     __shared__ double s_sph[SPH_CHUNK][4];
     __shared__ SphereRec s_rec[SMALL ? SPH_CHUNK_SMALL : 1];
-    __shared__ uint16_t s_cand[SMALL ? 1 : WPB][SMALL ? 1 : 64][CAND_MAX];   // per lane: spheres the screening kept
+    // per lane: the spheres the screening kept (element k of thread t at [k][t])
+    static_assert(CAND_MAX <= HIER_CAP, "the plain screening loop uses the same list");
+    __shared__ uint16_t s_list[SMALL ? 1 : HIER_CAP][SMALL ? 1 : BLOCK];
     __shared__ SceneConst s_sc;
     static_assert(sizeof(SceneConst) % 8 == 0, "SceneConst is copied in 8-byte words");
 
@@ -236,14 +238,12 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
         const double d_o = dot(d, o);
         double best = __builtin_inf();
         int sid = -1;
-        if (!SMALL && active) {
-            // Many spheres: float32 screening of all pairs (table read through the scalar unit,
-            // four pairs per step), the float64 test only for the pairs it cannot rule out.
-            // The screening looks at the ray's whole line, so any point of the line can stand in
-            // for the origin: the one nearest to the middle of the spheres keeps the float32
-            // coordinates (and with them the error bound) small for rays that start far away.
-            typedef const __attribute__((address_space(4))) CullPair* ConstCull;
-            ConstCull table = (ConstCull)(uintptr_t)D.cull;
+        if (!SMALL && __ballot(active) != 0) {
+            // Many spheres: float32 screening (rt_math.h: cull_test) first, the float64 test only
+            // for the spheres it cannot rule out.  The screening looks at the ray's whole line, so
+            // any point of the line can stand in for the origin: the one nearest to the middle of
+            // the spheres keeps the float32 coordinates (and with them the error bound) small for
+            // rays that start far away.
             const V3 ref = {D.cull_ref[0], D.cull_ref[1], D.cull_ref[2]};
             const V3 on = o + dot(ref - o, d) * d;
             const float ox = (float)on.x, oy = (float)on.y, oz = (float)on.z;
@@ -254,41 +254,78 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int leve
                 double lo, hi;
                 if (sphere_roots(o, d, d_o, g[0], g[1], g[2], g[3] * g[3], lo, hi)) {
                     const double tt = lo > 0 ? lo : hi;
-                    // ties go to the later sphere, as the reference's min_t == t update does
-                    if (tt > 0 && tt <= best) { best = tt; sid = i; }
+                    // ties go to the later sphere, as the reference's min_t == t update does in its
+                    // loop over all spheres; written so that the order of the tests does not matter
+                    if (tt > 0 && (tt < best || (tt == best && i > sid))) { best = tt; sid = i; }
                 }
             };
-            // The survivors of a lane go to its own short list first and are tested together
-            // afterwards, in sphere order: lanes survive at different spheres, testing on the
-            // spot would run the float64 code once per sphere that any lane of the wave keeps.
-            uint16_t* mine = s_cand[wave][lane];
-            int n_mine = 0;
-            auto flush = [&]() {
-                for (int k = 0; __ballot(k < n_mine) != 0; ++k)   // the longest list of the active lanes
-                    if (k < n_mine) exact(mine[k]);
-                n_mine = 0;
-            };
-            const int np = ((S + 7) >> 3) << 2;   // the table is padded with blank entries
-            for (int p = 0; p < np; p += 4) {
-                v2f t[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    CullPair cp;
-#pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        cp.cx[w] = table[p + k].cx[w]; cp.cy[w] = table[p + k].cy[w]; cp.cz[w] = table[p + k].cz[w];
-                        cp.r[w] = table[p + k].r[w]; cp.e[w] = table[p + k].e[w];
-                    }
-                    t[k] = cull_test(cp, ox, oy, oz, dx, dy, dz, e_ray);
+            const LaneList list = {&s_list[0][SMALL ? 0 : tid]};
+            bool every_sphere = active;   // lanes that screen the whole table
+            if (D.hier_top_groups) {
+                // Bounding-sphere hierarchy: a few dozen tests instead of one per sphere.  The ray
+                // is walked in windows that grow by a factor of 4: most rays of a scene full of
+                // spheres end close to where they start (inside a sphere, at a neighbour), and a
+                // hit inside the window ends the search - everything not yet looked at begins
+                // beyond the window.  The ray starts at s_o on the line, measured from `on`.
+                const double s_o = -dot(ref - o, d);
+                HierWindow win;
+                win.s_from = (float)(s_o - 1e-6 * fabs(s_o)) - e_ray;   // rounded down
+                win.s_prev = __builtin_nanf("");
+                float reach = D.hier_window;
+                bool pending = active, overflowed = false;
+                while (__ballot(pending) != 0) {
+                    const bool last = !(reach < D.hier_extent);   // the rest of the ray
+                    win.s_to = last ? __builtin_inff() : (float)(s_o + reach);
+                    win.s_best = (best < __builtin_inf()) ? (float)((s_o + best) + 1e-6 * fabs(s_o + best)) + e_ray : __builtin_inff();
+                    bool more;
+                    const int n = hier_candidates(D, list, pending, ox, oy, oz, dx, dy, dz, e_ray, win, more);
+                    for (int k = 0; __ballot(k < n) != 0; ++k)
+                        if (k < n) exact(list[k]);
+                    if (n < 0) { overflowed = true; pending = false; }   // the list overflowed
+                    // nothing left beyond the window, or a hit before the window's end: whatever has
+                    // not been looked at begins later
+                    if (last || !more || (s_o + best) < (double)win.s_to - (double)e_ray - 1e-6 * fabs(s_o + best)) pending = false;
+                    win.s_prev = win.s_to;
+                    reach *= 4;
                 }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (!(t[k].x > 0) && 2 * (p + k) < S) mine[n_mine++] = (uint16_t)(2 * (p + k));
-                    if (!(t[k].y > 0) && 2 * (p + k) + 1 < S) mine[n_mine++] = (uint16_t)(2 * (p + k) + 1);
-                }
-                if (__ballot(n_mine > CAND_MAX - 8) != 0) flush();   // some lane's list is nearly full
+                every_sphere = overflowed;
             }
-            flush();
+            if (every_sphere) {
+                // All pairs of the table (read through the scalar unit, four pairs per step).  The
+                // survivors of a lane go to its own short list first and are tested together
+                // afterwards, in sphere order: lanes survive at different spheres, testing on the
+                // spot would run the float64 code once per sphere that any lane of the wave keeps.
+                typedef const __attribute__((address_space(4))) CullPair* ConstCull;
+                ConstCull table = (ConstCull)(uintptr_t)D.cull;
+                const LaneList mine = list;
+                int n_mine = 0;
+                auto flush = [&]() {
+                    for (int k = 0; __ballot(k < n_mine) != 0; ++k)   // the longest list of the active lanes
+                        if (k < n_mine) exact(mine[k]);
+                    n_mine = 0;
+                };
+                const int np = ((S + 7) >> 3) << 2;   // the table is padded with blank entries
+                for (int p = 0; p < np; p += 4) {
+                    v2f t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        CullPair cp;
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            cp.cx[w] = table[p + k].cx[w]; cp.cy[w] = table[p + k].cy[w]; cp.cz[w] = table[p + k].cz[w];
+                            cp.r[w] = table[p + k].r[w]; cp.e[w] = table[p + k].e[w];
+                        }
+                        t[k] = cull_test(cp, ox, oy, oz, dx, dy, dz, e_ray);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (!(t[k].x > 0) && 2 * (p + k) < S) mine[n_mine++] = (uint16_t)(2 * (p + k));
+                        if (!(t[k].y > 0) && 2 * (p + k) + 1 < S) mine[n_mine++] = (uint16_t)(2 * (p + k) + 1);
+                    }
+                    if (__ballot(n_mine > CAND_MAX - 8) != 0) flush();   // some lane's list is nearly full
+                }
+                flush();
+            }
         }
         if (SMALL && active) {
             // few spheres, all in LDS: the float64 test for every one, two per iteration (two

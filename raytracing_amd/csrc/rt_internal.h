@@ -50,6 +50,8 @@ struct SceneConst {
 };
 
 // Everything a kernel needs, passed by value.
+struct Group8;
+
 struct Dev {
     // scene
     const double* geom;  // [S][4] centre, radius
@@ -60,6 +62,15 @@ struct Dev {
     int32_t n_lights;
     double cull_ref[3];  // a point in the middle of the (moderately sized) spheres, see the float32 screening
     const float* cull;   // [ceil(S / 8) * 4][10] float32 screening table, two spheres per entry (CullPair)
+    // bounding-sphere hierarchy over the spheres (rt_hier.h), eight entries per Group8; hier_top_groups == 0: none
+    const Group8* hier_top;        // [hier_top_groups]: blocks of 64 spheres, then loose spheres, then padding
+    const uint32_t* hier_top_ref;  // [8 * hier_top_groups] block index, HIER_LOOSE | sphere, or HIER_NONE
+    const Group8* hier_mid;        // [blocks]: the 8 clusters of each block
+    const Group8* hier_leaf;       // [blocks * 8]: the 8 spheres of each cluster
+    const uint16_t* hier_ids;      // [blocks * 8 * 8] sphere index of each cluster slot, or HIER_NO_SPHERE
+    int32_t hier_top_groups;
+    float hier_window;             // length of the first stretch of a ray that k_trace searches (then x4, x16, ...)
+    float hier_extent;             // from this length on a stretch is the whole rest of the ray
     // static tree
     const int32_t* node_a;
     const int32_t* node_b;

@@ -32,6 +32,7 @@
 #endif
 
 #include "rt_math.h"
+#include "rt_hier.h"
 #include "rt_geometry.hip"
 #include "rt_samples.hip"
 #include "rt_lighting.hip"

@@ -36,66 +36,81 @@ __device__ __forceinline__ double pow_shininess(double x, double sh) {
 // RGB transmittance along a shadow ray (reference objects.py:274-285): every sphere
 // with a positive far root multiplies by transparency * exp(-k * chord), whether or
 // not it lies beyond the light.
+typedef LaneList ShadowLists;   // per-lane list in LDS for the screening of many spheres (rt_hier.h)
 template <bool LDS>
-__device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere* s_sh, uint16_t* cand, V3 o, V3 d) {
+__device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere* s_sh, const ShadowLists& lists, V3 o, V3 d) {
     V3 mult = {1, 1, 1};
     const int S = D.S;
     const double d_o = dot(d, o);
     if (!LDS) {
         // many spheres: float32 screening first (see cull_test), the float64 test for the
-        // survivors of this lane, in sphere order
-        typedef const __attribute__((address_space(4))) CullPair* ConstCull;   // uniform reads through the scalar unit
-        ConstCull table = (ConstCull)(uintptr_t)D.cull;
+        // survivors of this lane, in sphere order (the order of the multiplications)
         const V3 ref = {D.cull_ref[0], D.cull_ref[1], D.cull_ref[2]};
         const V3 on = o + dot(ref - o, d) * d;
         const float ox = (float)on.x, oy = (float)on.y, oz = (float)on.z;
         const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
         const float e_ray = cull_ray_margin(on);
-        int n_mine = 0;
         bool opaque = false;
-        auto flush = [&]() {
-            for (int k = 0; __ballot(k < n_mine) != 0; ++k) {   // the longest list of the active lanes
-                if (k < n_mine && !opaque) {
-                    const int i = cand[k];
-                    const double* g = D.geom + (size_t)i * 4;
-                    double lo, hi;
-                    if (sphere_roots(o, d, d_o, g[0], g[1], g[2], g[3] * g[3], lo, hi) && hi > 0) {
-                        const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
-                        const double tr = m[11];
-                        if (tr == 0) {
-                            opaque = true;
-                        } else {
-                            const double chord = lo > 0 ? hi - lo : 0.0;
-                            mult.x *= tr * exp(-(m[14] * m[15]) * chord);
-                            mult.y *= tr * exp(-(m[14] * m[16]) * chord);
-                            mult.z *= tr * exp(-(m[14] * m[17]) * chord);
-                        }
-                    }
+        auto occluder = [&](int i) {
+            const double* g = D.geom + (size_t)i * 4;
+            double lo, hi;
+            if (sphere_roots(o, d, d_o, g[0], g[1], g[2], g[3] * g[3], lo, hi) && hi > 0) {
+                const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
+                const double tr = m[11];
+                if (tr == 0) {
+                    opaque = true;
+                } else {
+                    const double chord = lo > 0 ? hi - lo : 0.0;
+                    mult.x *= tr * exp(-(m[14] * m[15]) * chord);
+                    mult.y *= tr * exp(-(m[14] * m[16]) * chord);
+                    mult.z *= tr * exp(-(m[14] * m[17]) * chord);
                 }
             }
-            n_mine = 0;
         };
-        const int np = ((S + 7) >> 3) << 2;
-        for (int p = 0; p < np; p += 4) {
-            v2f t[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                CullPair cp;
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    cp.cx[w] = table[p + k].cx[w]; cp.cy[w] = table[p + k].cy[w]; cp.cz[w] = table[p + k].cz[w];
-                    cp.r[w] = table[p + k].r[w]; cp.e[w] = table[p + k].e[w];
-                }
-                t[k] = cull_test(cp, ox, oy, oz, dx, dy, dz, e_ray);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!(t[k].x > 0) && 2 * (p + k) < S) cand[n_mine++] = (uint16_t)(2 * (p + k));
-                if (!(t[k].y > 0) && 2 * (p + k) + 1 < S) cand[n_mine++] = (uint16_t)(2 * (p + k) + 1);
-            }
-            if (__ballot(n_mine > CAND_MAX - 8) != 0) flush();
+        bool every_sphere = true;   // this lane screens the whole table
+        if (D.hier_top_groups) {
+            // the ray starts at -dot(ref - o, d) on the line, measured from `on`; rounded down
+            const double s_o = -dot(ref - o, d);
+            const float s_from = (float)(s_o - 1e-6 * fabs(s_o)) - e_ray;
+            const HierWindow whole = {s_from, __builtin_nanf(""), __builtin_inff(), __builtin_inff()};   // every occluder counts
+            bool more;
+            const int n = hier_candidates(D, lists, true, ox, oy, oz, dx, dy, dz, e_ray, whole, more);
+            for (int k = 0; __ballot(k < n) != 0; ++k)
+                if (k < n && !opaque) occluder(lists[k]);
+            every_sphere = n < 0;   // a list overflowed
         }
-        flush();
+        if (every_sphere) {
+            typedef const __attribute__((address_space(4))) CullPair* ConstCull;   // uniform reads through the scalar unit
+            ConstCull table = (ConstCull)(uintptr_t)D.cull;
+            const LaneList cand = lists;
+            int n_mine = 0;
+            auto flush = [&]() {
+                for (int k = 0; __ballot(k < n_mine) != 0; ++k)   // the longest list of the active lanes
+                    if (k < n_mine && !opaque) occluder(cand[k]);
+                n_mine = 0;
+            };
+            const int np = ((S + 7) >> 3) << 2;
+            for (int p = 0; p < np; p += 4) {
+                v2f t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    CullPair cp;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        cp.cx[w] = table[p + k].cx[w]; cp.cy[w] = table[p + k].cy[w]; cp.cz[w] = table[p + k].cz[w];
+                        cp.r[w] = table[p + k].r[w]; cp.e[w] = table[p + k].e[w];
+                    }
+                    t[k] = cull_test(cp, ox, oy, oz, dx, dy, dz, e_ray);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!(t[k].x > 0) && 2 * (p + k) < S) cand[n_mine++] = (uint16_t)(2 * (p + k));
+                    if (!(t[k].y > 0) && 2 * (p + k) + 1 < S) cand[n_mine++] = (uint16_t)(2 * (p + k) + 1);
+                }
+                if (__ballot(n_mine > CAND_MAX - 8) != 0) flush();
+            }
+            flush();
+        }
         if (opaque) return {0, 0, 0};
         return mult;
     }
@@ -150,7 +165,7 @@ struct SampleTerms {
     V3 Id, Is, kd, ks;
 };
 template <bool LDS>
-__device__ SampleTerms disk_sample_f64(const Dev& D, const ShadowSphere* s_sh, uint16_t* cand, const RtLight& Lt, double u_theta,
+__device__ SampleTerms disk_sample_f64(const Dev& D, const ShadowSphere* s_sh, const ShadowLists& cand, const RtLight& Lt, double u_theta,
                                        double u_rad, V3 Pb, V3 d, V3 n, V3 kdiff, V3 kspec, double shin) {
     const V3 lpos = ld3(Lt.position), xh = ld3(Lt.x_hat), yh = ld3(Lt.y_hat);
     const double theta = u_theta * 6.283185307179586;
@@ -371,7 +386,7 @@ __device__ void disk_light_mixed(const Dev& D, const ShadowSphere* s_sh, const R
 // :215-234 and objects.py:94-235).  entry: index of the hit in the shading list,
 // which is also the index of its disk-light samples in the packed sample buffer.
 template <bool LDS, bool MIXED, bool SIMPLE = false>
-__device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphere* s_sh, uint16_t* cand, int64_t entry, uint32_t info,
+__device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphere* s_sh, const ShadowLists& cand, int64_t entry, uint32_t info,
                             V3 Pb, V3 d, V3 n, const SurfaceMaterial& mat, unsigned& n_samples, unsigned& n_fallback) {
     const V3 kdiff = ld3(mat.kdiff), kspec = ld3(mat.kspec);
     const double shin = mat.shininess;
@@ -444,8 +459,9 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
     __shared__ double s_centre[TABLE][3];
     __shared__ SceneConst s_sc;
     __shared__ unsigned s_work[3];
-    __shared__ uint16_t s_cand[LDS ? 1 : BLOCK][CAND_MAX];   // per lane: spheres the shadow screening kept
+    __shared__ uint16_t s_lists[LDS ? 1 : HIER_CAP][LDS ? 1 : BLOCK];   // per lane: spheres the shadow screening kept
     const int tid = threadIdx.x;
+    const ShadowLists lists = {&s_lists[0][LDS ? 0 : tid]};
     if (D.flags[0]) return;  // arena overflow: the frame is invalid, the host reports it
     if (tid < 3) s_work[tid] = 0;
     for (int i = tid; i < (int)(sizeof(SceneConst) / 8); i += BLOCK)
@@ -479,7 +495,7 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
         const SurfaceMaterial mat = LDS ? s_mat[sid] : surface_material(D.mat + (size_t)sid * RT_MAT_WIDTH);
         const Surface sf = surface_at(P, centre, info & I_INSIDE, eps);
         unsigned unsure = 0;
-        V3 surf = surface_color<LDS, MIXED, SIMPLE>(D, sc, s_sh, LDS ? nullptr : s_cand[tid], e, info, sf.Pb, d, sf.n, mat, my_samples, unsure);
+        V3 surf = surface_color<LDS, MIXED, SIMPLE>(D, sc, s_sh, lists, e, info, sf.Pb, d, sf.n, mat, my_samples, unsure);
         my_hits += 1;
         D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
         if (MIXED && unsure) {
@@ -503,8 +519,9 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
 template <bool LDS>
 __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
     __shared__ ShadowSphere s_sh[LDS ? SHADE_LDS_SPHERES : 1];
-    __shared__ uint16_t s_cand[LDS ? 1 : BLOCK][CAND_MAX];
+    __shared__ uint16_t s_lists[LDS ? 1 : HIER_CAP][LDS ? 1 : BLOCK];
     const int tid = threadIdx.x;
+    const ShadowLists lists = {&s_lists[0][LDS ? 0 : tid]};
     if (D.flags[0]) return;
     const int total = D.flags[1];
     if (total == 0) return;
@@ -527,7 +544,7 @@ __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
         V3 d = {D.dx[ray], D.dy[ray], D.dz[ray]};
         const Surface sf = surface_at(P, ld3(D.geom + (size_t)sid * 4), info & I_INSIDE, eps);
         unsigned a = 0, b = 0;
-        V3 surf = surface_color<LDS, false>(D, sc, s_sh, LDS ? nullptr : s_cand[tid], e, info, sf.Pb, d, sf.n,
+        V3 surf = surface_color<LDS, false>(D, sc, s_sh, lists, e, info, sf.Pb, d, sf.n,
                                             surface_material(D.mat + (size_t)sid * RT_MAT_WIDTH), a, b);
         D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
     }

@@ -43,6 +43,7 @@ with Renderer(scene) as r:
     c = r.counters()
     img = r.image()
 print(json.dumps({"config": label, "rays": int(c["rays"]), "hits": int(c["hits"]), "samples": int(n_samples),
+                  "shaded_hits": int(c["shaded_hits"]), "live_hits": int(c["live_hits"]),
                   "ms_per_frame": (t4 - t3) / steps * 1e3, "Mrays_per_s": c["rays"] / ((t4 - t3) / steps) / 1e6,
                   "kernel_ms": {k: v["ms"] / steps for k, v in prof.items()},
                   "first_trace_s": t1 - t0, "draw_upload_s": t2 - t1, "arena_rays_used": int(c["arena_rays_used"]),
