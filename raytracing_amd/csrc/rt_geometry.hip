@@ -68,7 +68,7 @@ struct SphereRec {   // per-sphere constants of the hit record
 };
 
 template <bool SMALL>   // SMALL: at most SPH_CHUNK_SMALL spheres, all constants in LDS
-__global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_trace(Dev D, int level) {
+__global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY) void k_trace(Dev D, int level) {
     constexpr int SPH_CHUNK = SMALL ? SPH_CHUNK_SMALL : 1;
     __shared__ NodeRec s_node[MAX_LEVEL_NODES];
     __shared__ double s_sph[SPH_CHUNK][4];

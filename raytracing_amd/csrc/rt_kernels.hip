@@ -27,6 +27,9 @@
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 4   // waves per SIMD requested for k_trace
 #endif
+#ifndef RT_TRACE_WAVES_MANY
+#define RT_TRACE_WAVES_MANY 4   // the same for the many-sphere variant of k_trace
+#endif
 #ifndef RT_MIXED_WAVES
 #define RT_MIXED_WAVES 2   // waves per SIMD requested for the mixed-precision surface kernel
 #endif
