@@ -3,7 +3,7 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--width 3840 --height 2160]
 
 Workload: the reference's example_1..4 scenes at 3840x2160 (the resolution
-BASELINE.json quotes the metric on), depths (3, 5), example_4 with 30 disk
+the headline metric is quoted on), depths (3, 5), example_4 with 30 disk
 samples per hit drawn from NumPy's stream seeded with 0.  One *step* renders
 all four frames: geometry of all bounce levels, lighting/shading and the
 bottom-up colour pass.  Scene buffers and the disk-light samples are resident

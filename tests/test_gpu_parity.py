@@ -232,7 +232,7 @@ def test_batch_sizes_in_caller_owned_device_memory(golden_dir):
 
 
 # Ray / hit / shadow-ray / random-number counts of the REFERENCE at 1920x1080 (seed 0),
-# recorded when the reference itself was run at that size (BASELINE.md section 2).
+# recorded when the reference itself was run at that size.
 FULL_HD_REFERENCE_COUNTS = {
     "example_1": dict(rays=37_336_983, shadow=20_571_993),
     "example_2": dict(rays=24_405_826, shadow=13_154_208),
