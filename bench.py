@@ -282,7 +282,7 @@ def main():
         "roofline": roofline,
         "rooflines": rooflines,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the host baseline is timed on single-GPU runs only
         out["cpu_baseline"] = cpu_baseline()
     frames.close()
     print(json.dumps(out))
