@@ -112,7 +112,7 @@ struct RtContext {
     DevBuf<Group8> hier_top, hier_mid, hier_leaf;
     DevBuf<uint32_t> hier_top_ref;
     DevBuf<uint16_t> hier_ids;
-    int hier_top_groups = 0;
+    int hier_top_groups = 0, hier_blocks = 0;
     float hier_window = 0, hier_extent = 0;
     DevBuf<SceneConst> sc;
     DevBuf<int32_t> node_a, node_b, node_branch, node_child, level_start;
@@ -164,7 +164,7 @@ struct RtContext {
     Dev dev() const {
         Dev D{};
         D.geom = geom.p; D.mat = mat.p; D.fres = fres.p; D.cull = cull.p; D.cull_ref[0] = cull_ref[0]; D.cull_ref[1] = cull_ref[1]; D.cull_ref[2] = cull_ref[2]; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
-        D.hier_top = hier_top.p; D.hier_top_ref = hier_top_ref.p; D.hier_mid = hier_mid.p; D.hier_leaf = hier_leaf.p; D.hier_ids = hier_ids.p; D.hier_top_groups = hier_top_groups; D.hier_window = hier_window; D.hier_extent = hier_extent;
+        D.hier_top = hier_top.p; D.hier_top_ref = hier_top_ref.p; D.hier_mid = hier_mid.p; D.hier_leaf = hier_leaf.p; D.hier_ids = hier_ids.p; D.hier_top_groups = hier_top_groups; D.hier_blocks = hier_blocks; D.hier_window = hier_window; D.hier_extent = hier_extent;
         D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
         D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.batch_slot = batch_slot; D.batch_slots = batch_slots; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
@@ -432,6 +432,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
             HIP_TRY(upload(ctx->hier_top_ref, H.top_ref));
             HIP_TRY(upload(ctx->hier_ids, H.ids));
             ctx->hier_top_groups = (int)H.top.size();
+            ctx->hier_blocks = H.blocks;
             // the windows of k_trace's search: a few sphere radii first; twice the distance from the
             // tables' reference point to the farthest grouped sphere covers every ray's way through them
             double reach = 0;

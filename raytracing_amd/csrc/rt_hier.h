@@ -146,7 +146,9 @@ __device__ __forceinline__ int hier_candidates(const Dev& D, LaneList C, bool ac
             if (m != 0) {
                 const int e = __builtin_ctzll(m);
                 m &= m - 1;
-                ref = D.hier_top_ref[8 * chunk + e];
+                // the blocks come first in the top list, in order; only other entries need the look-up
+                ref = 8 * chunk + e;
+                if ((int)ref >= D.hier_blocks) ref = D.hier_top_ref[ref];
                 if (ref == HIER_NONE) {
                     // padding (its table entry lies far away, but nothing is assumed about the test's outcome)
                 } else if (ref & HIER_LOOSE) {

@@ -69,6 +69,7 @@ struct Dev {
     const Group8* hier_leaf;       // [blocks * 8]: the 8 spheres of each cluster
     const uint16_t* hier_ids;      // [blocks * 8 * 8] sphere index of each cluster slot, or HIER_NO_SPHERE
     int32_t hier_top_groups;
+    int32_t hier_blocks;           // the first hier_blocks entries of the top list are the blocks 0, 1, 2, ...
     float hier_window;             // length of the first stretch of a ray that k_trace searches (then x4, x16, ...)
     float hier_extent;             // from this length on a stretch is the whole rest of the ray
     // static tree
