@@ -75,7 +75,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
     __shared__ SphereRec s_rec[SMALL ? SPH_CHUNK_SMALL : 1];
     // per lane: the spheres the screening kept (element k of thread t at [k][t])
     static_assert(CAND_MAX <= HIER_CAP, "the plain screening loop uses the same list");
-    __shared__ uint16_t s_list[SMALL ? 1 : HIER_CAP][SMALL ? 1 : BLOCK];
+    __shared__ uint16_t s_list[SMALL ? 1 : 2 * HIER_CAP][SMALL ? 1 : BLOCK];
     __shared__ SceneConst s_sc;
     static_assert(sizeof(SceneConst) % 8 == 0, "SceneConst is copied in 8-byte words");
 
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                     if (tt > 0 && (tt < best || (tt == best && i > sid))) { best = tt; sid = i; }
                 }
             };
-            const LaneList list = {&s_list[0][SMALL ? 0 : tid]};
+            const LaneList list = {&s_list[0][SMALL ? 0 : tid]}, clusters = {&s_list[SMALL ? 0 : HIER_CAP][SMALL ? 0 : tid]};
             bool every_sphere = active;   // lanes that screen the whole table
             if (D.hier_top_groups) {
                 // Bounding-sphere hierarchy: a few dozen tests instead of one per sphere.  The ray
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                     win.s_to = last ? __builtin_inff() : (float)(s_o + reach);
                     win.s_best = (best < __builtin_inf()) ? (float)((s_o + best) + 1e-6 * fabs(s_o + best)) + e_ray : __builtin_inff();
                     bool more;
-                    const int n = hier_candidates(D, list, pending, ox, oy, oz, dx, dy, dz, e_ray, win, more);
+                    const int n = hier_candidates(D, clusters, list, pending, ox, oy, oz, dx, dy, dz, e_ray, win, more);
                     for (int k = 0; __ballot(k < n) != 0; ++k)
                         if (k < n) exact(list[k]);
                     if (n < 0) { overflowed = true; pending = false; }   // the list overflowed

@@ -11,9 +11,9 @@
 // which alone decides - in ascending sphere order, as a loop over all spheres would.
 //
 // The top list is the same for all lanes and is read through the scalar unit; below it every lane
-// follows its own survivors.  The candidates go to a short per-lane list in LDS; a lane whose list
-// overflows reports that, and the caller screens all spheres for it (the plain loop over the
-// whole table).
+// follows its own survivors.  Clusters and candidates go to two short per-lane lists in LDS; a lane
+// whose lists overflow reports that, and the caller screens all spheres for it (the plain loop
+// over the whole table).
 #pragma once
 #include <math.h>
 
@@ -101,9 +101,9 @@ struct HierWindow {
 // the line through (ox, oy, oz) (a point of it near the reference point of the tables) with
 // direction (dx, dy, dz); e_ray as for cull_test.  Inactive lanes get 0.  Wave-uniform control flow.
 //
-// The survivors of the top list are kept as a bit mask per 64 entries and followed depth first:
-// block -> mask of its 8 clusters -> their spheres, the waves' lanes each following their own.
-__device__ __forceinline__ int hier_candidates(const Dev& D, LaneList C, bool active, float ox, float oy, float oz,
+// The survivors of the top list are kept as a bit mask per 64 entries; every lane then walks its
+// own blocks (their surviving clusters go to the list B), then its own clusters (candidates to C).
+__device__ __forceinline__ int hier_candidates(const Dev& D, LaneList B, LaneList C, bool active, float ox, float oy, float oz,
                                                float dx, float dy, float dz, float e_ray, const HierWindow& win, bool& more) {
     typedef const __attribute__((address_space(4))) Group8* ConstGroups;   // uniform reads through the scalar unit
     ConstGroups top = (ConstGroups)(uintptr_t)D.hier_top;
@@ -115,8 +115,10 @@ __device__ __forceinline__ int hier_candidates(const Dev& D, LaneList C, bool ac
     const float s_far = fminf(win.s_to, win.s_best);
     more = false;
     // an entry below the top list: met by the line, not behind the origin, not beyond a known hit
+    // (one three-way maximum; a NaN operand is ignored by it, so an entry with non-finite data stays)
     auto keep = [&](const CullRange& r, int w) {
-        return !(r.miss[w] > 0) && !(r.behind[w] > 0) && !(r.near[w] > win.s_best);
+        const v2f beyond = r.near - win.s_best;
+        return !(__builtin_fmaxf(__builtin_fmaxf(r.miss[w], r.behind[w]), beyond[w]) > 0);
     };
     for (int chunk = 0; chunk < D.hier_top_groups; chunk += 8) {
         // 1. up to 64 entries of the top list (blocks, loose spheres, padding)
@@ -139,44 +141,47 @@ __device__ __forceinline__ int hier_candidates(const Dev& D, LaneList C, bool ac
             }
         }
         if (!active) m = 0;
-        // 2. every lane follows its own surviving entries
+        // 2. every lane takes its own surviving entries one by one: the clusters of a block that
+        //    survive go to the lane's cluster list, a loose sphere is a candidate already
+        int nB = 0;
         while (__ballot(m != 0) != 0) {
-            unsigned clusters = 0;   // surviving clusters of the lane's current block
-            uint32_t ref = 0;
             if (m != 0) {
                 const int e = __builtin_ctzll(m);
                 m &= m - 1;
                 // the blocks come first in the top list, in order; only other entries need the look-up
-                ref = 8 * chunk + e;
+                uint32_t ref = 8 * chunk + e;
                 if ((int)ref >= D.hier_blocks) ref = D.hier_top_ref[ref];
                 if (ref == HIER_NONE) {
                     // padding (its table entry lies far away, but nothing is assumed about the test's outcome)
                 } else if (ref & HIER_LOOSE) {
-                    push(ref & 0xffffu);   // a loose sphere is a candidate already
+                    push(ref & 0xffffu);
                 } else {
                     const Group8Regs g = load_group(D.hier_mid, ref);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const CullRange r = cull_range(g.pair(0, k), g.pair(1, k), g.pair(2, k), g.pair(3, k), ox, oy, oz, dx, dy, dz, e_ray, win.s_from);
-                        if (keep(r, 0)) clusters |= 1u << (2 * k);
-                        if (keep(r, 1)) clusters |= 2u << (2 * k);
+#pragma unroll
+                        for (int w = 0; w < 2; ++w)
+                            if (keep(r, w)) {
+                                if (nB < HIER_CAP) B[nB++] = (uint16_t)(ref * 8 + 2 * k + w); else overflow = true;
+                            }
                     }
                 }
             }
-            while (__ballot(clusters != 0) != 0) {
-                if (clusters != 0) {
-                    const uint32_t cl = ref * 8 + __builtin_ctz(clusters);
-                    clusters &= clusters - 1;
-                    const Group8Regs g = load_group(D.hier_leaf, cl);
-                    const uint4 ids = reinterpret_cast<const uint4*>(D.hier_ids)[cl];   // 8 sphere indices of 16 bits
-                    const uint32_t id2[4] = {ids.x, ids.y, ids.z, ids.w};
+        }
+        // 3. the spheres of the listed clusters (as many steps as the longest list of the wave)
+        for (int i = 0; __ballot(i < nB) != 0; ++i) {
+            if (i < nB) {
+                const uint32_t cl = B[i];
+                const Group8Regs g = load_group(D.hier_leaf, cl);
+                const uint4 ids = reinterpret_cast<const uint4*>(D.hier_ids)[cl];   // 8 sphere indices of 16 bits
+                const uint32_t id2[4] = {ids.x, ids.y, ids.z, ids.w};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const CullRange r = cull_range(g.pair(0, k), g.pair(1, k), g.pair(2, k), g.pair(3, k), ox, oy, oz, dx, dy, dz, e_ray, win.s_from);
-                        const uint32_t s0 = id2[k] & 0xffffu, s1 = id2[k] >> 16;
-                        if (keep(r, 0) && s0 != HIER_NO_SPHERE) push(s0);
-                        if (keep(r, 1) && s1 != HIER_NO_SPHERE) push(s1);
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    const CullRange r = cull_range(g.pair(0, k), g.pair(1, k), g.pair(2, k), g.pair(3, k), ox, oy, oz, dx, dy, dz, e_ray, win.s_from);
+                    const uint32_t s0 = id2[k] & 0xffffu, s1 = id2[k] >> 16;
+                    if (keep(r, 0) && s0 != HIER_NO_SPHERE) push(s0);
+                    if (keep(r, 1) && s1 != HIER_NO_SPHERE) push(s1);
                 }
             }
         }

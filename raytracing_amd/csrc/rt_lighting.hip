@@ -36,7 +36,9 @@ __device__ __forceinline__ double pow_shininess(double x, double sh) {
 // RGB transmittance along a shadow ray (reference objects.py:274-285): every sphere
 // with a positive far root multiplies by transparency * exp(-k * chord), whether or
 // not it lies beyond the light.
-typedef LaneList ShadowLists;   // per-lane list in LDS for the screening of many spheres (rt_hier.h)
+struct ShadowLists {   // per-lane lists in LDS for the screening of many spheres (rt_hier.h)
+    LaneList clusters, spheres;
+};
 template <bool LDS>
 __device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere* s_sh, const ShadowLists& lists, V3 o, V3 d) {
     V3 mult = {1, 1, 1};
@@ -74,15 +76,15 @@ __device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere
             const float s_from = (float)(s_o - 1e-6 * fabs(s_o)) - e_ray;
             const HierWindow whole = {s_from, __builtin_nanf(""), __builtin_inff(), __builtin_inff()};   // every occluder counts
             bool more;
-            const int n = hier_candidates(D, lists, true, ox, oy, oz, dx, dy, dz, e_ray, whole, more);
+            const int n = hier_candidates(D, lists.clusters, lists.spheres, true, ox, oy, oz, dx, dy, dz, e_ray, whole, more);
             for (int k = 0; __ballot(k < n) != 0; ++k)
-                if (k < n && !opaque) occluder(lists[k]);
+                if (k < n && !opaque) occluder(lists.spheres[k]);
             every_sphere = n < 0;   // a list overflowed
         }
         if (every_sphere) {
             typedef const __attribute__((address_space(4))) CullPair* ConstCull;   // uniform reads through the scalar unit
             ConstCull table = (ConstCull)(uintptr_t)D.cull;
-            const LaneList cand = lists;
+            const LaneList cand = lists.spheres;
             int n_mine = 0;
             auto flush = [&]() {
                 for (int k = 0; __ballot(k < n_mine) != 0; ++k)   // the longest list of the active lanes
@@ -459,9 +461,9 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
     __shared__ double s_centre[TABLE][3];
     __shared__ SceneConst s_sc;
     __shared__ unsigned s_work[3];
-    __shared__ uint16_t s_lists[LDS ? 1 : HIER_CAP][LDS ? 1 : BLOCK];   // per lane: spheres the shadow screening kept
+    __shared__ uint16_t s_lists[LDS ? 1 : 2 * HIER_CAP][LDS ? 1 : BLOCK];   // per lane: spheres the shadow screening kept
     const int tid = threadIdx.x;
-    const ShadowLists lists = {&s_lists[0][LDS ? 0 : tid]};
+    const ShadowLists lists = {{&s_lists[LDS ? 0 : HIER_CAP][LDS ? 0 : tid]}, {&s_lists[0][LDS ? 0 : tid]}};
     if (D.flags[0]) return;  // arena overflow: the frame is invalid, the host reports it
     if (tid < 3) s_work[tid] = 0;
     for (int i = tid; i < (int)(sizeof(SceneConst) / 8); i += BLOCK)
@@ -519,9 +521,9 @@ __global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(D
 template <bool LDS>
 __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
     __shared__ ShadowSphere s_sh[LDS ? SHADE_LDS_SPHERES : 1];
-    __shared__ uint16_t s_lists[LDS ? 1 : HIER_CAP][LDS ? 1 : BLOCK];
+    __shared__ uint16_t s_lists[LDS ? 1 : 2 * HIER_CAP][LDS ? 1 : BLOCK];
     const int tid = threadIdx.x;
-    const ShadowLists lists = {&s_lists[0][LDS ? 0 : tid]};
+    const ShadowLists lists = {{&s_lists[LDS ? 0 : HIER_CAP][LDS ? 0 : tid]}, {&s_lists[0][LDS ? 0 : tid]}};
     if (D.flags[0]) return;
     const int total = D.flags[1];
     if (total == 0) return;
