@@ -605,7 +605,19 @@ struct LevelTables {
     const uint32_t* child;   // [nn][4]
     const uint32_t* pre;     // [nn][16]; the shading list is level-wide, its entry is 0
 };
-__device__ __forceinline__ LevelTables stage_level_tables(const Dev& D, int level, int* s_dyn, int tid) {
+__device__ __forceinline__ int find_node(const NodeRec* node, int nn, int t) {
+    int lo = 0, hi = nn - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (node[mid].tile_end > t) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+// Stages the tables for the workgroup's tiles [t_first, t_last]: the tile layout of every node of
+// the level (the node search needs it), child slots and counter values only of the nodes those
+// tiles belong to (usually one or two of up to a few hundred; the rest of the arrays stays
+// unwritten).  Contains a barrier; the caller synchronises once more before reading.
+__device__ __forceinline__ LevelTables stage_level_tables(const Dev& D, int level, int* s_dyn, int tid, int t_first, int t_last) {
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
     NodeRec* node = reinterpret_cast<NodeRec*>(s_dyn);
     uint32_t* child = reinterpret_cast<uint32_t*>(node + nn);
@@ -615,27 +627,21 @@ __device__ __forceinline__ LevelTables stage_level_tables(const Dev& D, int leve
         const int t0 = D.node_tile0[k];
         node[i] = {t0 + D.node_ntiles[k], t0, D.node_n[k], 0};
     }
-    for (int i = tid; i < nn * 4; i += BLOCK) {
-        const int c = i & 3;
+    __syncthreads();
+    const int n_first = find_node(node, nn, t_first), n_last = find_node(node, nn, t_last);
+    const int span = n_last - n_first + 1;
+    for (int j = tid; j < span * 4; j += BLOCK) {
+        const int i = n_first * 4 + j, c = i & 3;
         const int ch = c < 3 ? D.node_child[(k0 + (i >> 2)) * 3 + c] : -1;
         child[i] = ch >= 0 ? D.node_start[ch] : 0u;
     }
-    for (int i = tid; i < nn * 16; i += BLOCK) {
-        const int c = i & 15;
+    for (int j = tid; j < span * 16; j += BLOCK) {
+        const int i = n_first * 16 + j, c = i & 15;
         pre[i] = (c < NCNT && c != C_SHADE) ? D.node_pre[(size_t)(k0 + (i >> 4)) * NCNT + c] : 0u;
     }
     return {node, child, pre};
 }
 static_assert(NCNT <= 16, "counter tables in LDS have 16 columns");
-__device__ __forceinline__ int find_node(const NodeRec* node, int nn, int t) {
-    int lo = 0, hi = nn - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (node[mid].tile_end > t) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
-
 // Ordered compaction: every child slot of the next level learns its parent, and the
 // hits that need lighting are appended to the dense shading list.
 __global__ __launch_bounds__(BLOCK) void k_link(Dev D, int level) {
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) void k_link(Dev D, int level) {
     const int t_begin = wid * q;
     const int t_end = min(nt, t_begin + q);
     if (blockIdx.x * WPB * q >= nt) return;   // nothing for this workgroup
-    const LevelTables T = stage_level_tables(D, level, s_dyn, tid);
+    const LevelTables T = stage_level_tables(D, level, s_dyn, tid, blockIdx.x * WPB * q, min(nt, (int)(blockIdx.x + 1) * WPB * q) - 1);
     const bool has_children = level + 1 < D.n_levels;
     const int shade_base = D.lvl_shade_base[level];
     // counters whose ranks are needed: children, shade items, and what sample addressing uses

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
     const int t_begin = wid * q;
     const int t_end = min(nt, t_begin + q);
     if (blockIdx.x * WPB * q >= nt) return;   // nothing for this workgroup
-    const LevelTables T = stage_level_tables(D, level, s_dyn, tid);
+    const LevelTables T = stage_level_tables(D, level, s_dyn, tid, blockIdx.x * WPB * q, min(nt, (int)(blockIdx.x + 1) * WPB * q) - 1);
     auto sphere_consts = [&](int i) -> CombineSphere {
         const double* m = D.mat + (size_t)i * RT_MAT_WIDTH;
         return {m[11], -m[14] * m[15], -m[14] * m[16], -m[14] * m[17]};
