@@ -151,6 +151,20 @@ int rt_build_tree(int32_t max_reflection_depth, int32_t max_refraction_depth,
                   int32_t *a, int32_t *b, int32_t *parent, int32_t *branch, int32_t *child,
                   int32_t *level, int32_t *level_start);
 
+/* The grouping rt_set_scene builds over scenes with more than 64 spheres so that the nearest-hit
+ * and shadow searches (reference objects.py:288-299 and :274-285, loops over every sphere) only test
+ * spheres a ray can touch: blocks of 64 spheres made of 8 clusters of 8, each with a bounding
+ * sphere; spheres far larger than the typical one stay "loose".  Pure host code (usable without a
+ * GPU), exported so that the grouping can be checked.  sphere_geom: [n][4] centre and radius.
+ * Pass NULL arrays to query the counts only.
+ * sphere_of_slot: [n_blocks * 64] sphere index of every cluster slot (slot = block * 64 + cluster
+ * * 8 + place), 0xFFFF for padding; cluster_bound: [n_blocks * 8][4] and block_bound: [n_blocks][4]
+ * centre and radius in float32 as the device tests them (radius = bounding radius + the error
+ * allowance of the float32 test; padding clusters have radius 0 and lie far away);
+ * loose_spheres: [n_loose]. */
+int rt_build_hierarchy(const double *sphere_geom, int64_t n, int32_t *n_blocks, int32_t *n_loose,
+                       uint16_t *sphere_of_slot, float *cluster_bound, float *block_bound, int32_t *loose_spheres);
+
 /* Create a context on GPU `device`.  `stream` is a hipStream_t to launch on
  * (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a private one. */
 int rt_create(int32_t device, void *stream, RtContext **out);

@@ -91,6 +91,8 @@ SIGNATURES = {
     "rt_get_node_counts": (C.c_int, [_P, _I64P, _I64P, _I64P]),
     "rt_set_sample_layout": (C.c_int, [_P, _I64P, C.c_int64]),
     "rt_upload_samples": (C.c_int, [_P, C.c_int64, _F64P, C.c_int64]),
+    "rt_build_hierarchy": (C.c_int, [_F64P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint16),
+                                     C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "rt_mt19937_jump_poly": (C.c_int, [C.c_int32, C.POINTER(C.c_uint32)]),
     "rt_set_sample_layout_global": (C.c_int, [_P, _I64P, _I64P, _I64P, C.c_int64]),
     "rt_generate_samples": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
@@ -155,6 +157,25 @@ def mt19937_jump_poly(k):
     out = np.empty(624, dtype=np.uint32)
     _check(load_library().rt_mt19937_jump_poly(int(k), out.ctypes.data_as(C.POINTER(C.c_uint32))))
     return out
+
+
+def build_hierarchy_native(sphere_geom):
+    """The sphere grouping of many-sphere scenes as the library builds it (host code only, no GPU
+    needed): ``(sphere_of_slot (blocks, 8, 8) uint16, cluster_bound (blocks, 8, 4) float32,
+    block_bound (blocks, 4) float32, loose_spheres int32)``."""
+    lib = load_library()
+    g = np.ascontiguousarray(sphere_geom, dtype=np.float64).reshape(-1, 4)
+    nb, nl = C.c_int32(), C.c_int32()
+    gp = g.ctypes.data_as(_F64P)
+    _check(lib.rt_build_hierarchy(gp, g.shape[0], C.byref(nb), C.byref(nl), None, None, None, None))
+    slots = np.empty((nb.value, 8, 8), dtype=np.uint16)
+    clusters = np.empty((nb.value, 8, 4), dtype=np.float32)
+    blocks = np.empty((nb.value, 4), dtype=np.float32)
+    loose = np.empty(nl.value, dtype=np.int32)
+    _check(lib.rt_build_hierarchy(gp, g.shape[0], C.byref(nb), C.byref(nl), slots.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                  clusters.ctypes.data_as(C.POINTER(C.c_float)), blocks.ctypes.data_as(C.POINTER(C.c_float)),
+                                  loose.ctypes.data_as(C.POINTER(C.c_int32))))
+    return slots, clusters, blocks, loose
 
 
 def build_tree_native(max_reflection_depth, max_refraction_depth):

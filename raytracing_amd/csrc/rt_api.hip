@@ -287,6 +287,24 @@ int rt_build_tree(int32_t refl, int32_t refr, int32_t* n_nodes, int32_t* n_level
     return RT_OK;
 }
 
+int rt_build_hierarchy(const double* sphere_geom, int64_t n, int32_t* n_blocks, int32_t* n_loose, uint16_t* sphere_of_slot,
+                       float* cluster_bound, float* block_bound, int32_t* loose_spheres) {
+    if (n < 0 || n >= 0xFFFF || (n > 0 && !sphere_geom)) return fail(RT_ERR_INVALID, "sphere_geom must hold 0 <= n < 65535 spheres");
+    const HostHierarchy H = build_hierarchy(sphere_geom, (size_t)n);
+    if (n_blocks) *n_blocks = H.blocks;
+    if (n_loose) *n_loose = H.loose;
+    if (sphere_of_slot) memcpy(sphere_of_slot, H.ids.data(), H.ids.size() * sizeof(uint16_t));
+    auto entry = [](const Group8& g, int k, float* out) { out[0] = g.cx[k]; out[1] = g.cy[k]; out[2] = g.cz[k]; out[3] = g.re[k]; };
+    if (cluster_bound)
+        for (int c = 0; c < H.blocks * 8; ++c) entry(H.mid[c / 8], c % 8, cluster_bound + (size_t)c * 4);
+    if (block_bound)
+        for (int b = 0; b < H.blocks; ++b) entry(H.top[b / 8], b % 8, block_bound + (size_t)b * 4);
+    if (loose_spheres)
+        for (size_t e = 0, i = 0; e < H.top_ref.size(); ++e)
+            if (H.top_ref[e] != HIER_NONE && (H.top_ref[e] & HIER_LOOSE)) loose_spheres[i++] = (int32_t)(H.top_ref[e] & 0xffffu);
+    return RT_OK;
+}
+
 int rt_create(int32_t device, void* stream, RtContext** out) {
     if (!out) return fail(RT_ERR_INVALID, "out is null");
     *out = nullptr;

@@ -122,3 +122,52 @@ def test_mt19937_jump_polynomial_advances_the_window(k):
 def test_mt19937_jump_polynomial_range():
     with pytest.raises(_native.RtError):
         _native.mt19937_jump_poly(48)
+
+
+# ---------------------------------------------------------------------------------------------
+# The sphere grouping of many-sphere scenes (host code of the library): every sphere has exactly one
+# place, and every bounding sphere contains what it bounds - the property the device's "the ray misses
+# the bound, so it misses every member" rests on.
+@pytest.mark.parametrize("n,seed", [(65, 0), (1000, 1), (4096, 2), (5003, 3)])
+def test_hierarchy_partition_and_bounds(n, seed):
+    from raytracing_amd._native import build_hierarchy_native
+    rs = np.random.RandomState(seed)
+    geom = np.column_stack([rs.uniform(2, 60, n), rs.uniform(-25, 25, n), rs.uniform(0.3, 12, n), rs.uniform(0.15, 0.6, n)])
+    geom[0] = [4.0, 0.0, -1.0e7, 1.0e7]                       # a ground sphere: far larger than the rest
+    if n > 500:
+        geom[7] = geom[8]                                     # two identical spheres
+        geom[9, 3] = 0.0                                      # a point
+    slots, clusters, blocks, loose = build_hierarchy_native(geom)
+    assert list(loose) == [0]
+    placed = slots[slots != 0xFFFF]
+    assert sorted(placed.tolist() + list(loose)) == list(range(n))          # one place each
+    assert blocks.shape[0] == -(-(n - 1) // 64)
+    c, r = geom[:, :3], np.abs(geom[:, 3])
+    for b in range(slots.shape[0]):
+        in_block = []
+        for k in range(8):
+            members = slots[b, k][slots[b, k] != 0xFFFF].astype(int)
+            if len(members) == 0:
+                assert clusters[b, k, 3] == 0 and clusters[b, k, 0] > 1e14   # padding: far away
+                continue
+            in_block += members.tolist()
+            reach = np.linalg.norm(c[members] - clusters[b, k, :3].astype(float), axis=1) + r[members]
+            assert reach.max() <= float(clusters[b, k, 3])
+        reach = np.linalg.norm(c[in_block] - blocks[b, :3].astype(float), axis=1) + r[in_block]
+        assert reach.max() <= float(blocks[b, 3])
+    # the groups are compact: a block's bound is far smaller than the scene
+    assert np.median(blocks[:, 3]) < (30.0 if n >= 1000 else 60.0)
+
+
+def test_hierarchy_degenerate_inputs():
+    from raytracing_amd._native import build_hierarchy_native
+    slots, clusters, blocks, loose = build_hierarchy_native(np.zeros((0, 4)))
+    assert slots.shape[0] == 0 and len(loose) == 0
+    same = np.tile([1.0, 2.0, 3.0, 0.5], (130, 1))           # all spheres identical
+    slots, clusters, blocks, loose = build_hierarchy_native(same)
+    assert len(loose) == 0 and sorted(slots[slots != 0xFFFF].tolist()) == list(range(130))
+    bad = same.copy()
+    bad[5, 0] = np.nan
+    bad[6, 3] = np.inf
+    slots, clusters, blocks, loose = build_hierarchy_native(bad)
+    assert sorted(loose.tolist()) == [5, 6]                  # non-finite spheres are never grouped
