@@ -286,7 +286,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                     // not been looked at begins later
                     if (last || !more || (s_o + best) < (double)win.s_to - (double)e_ray - 1e-6 * fabs(s_o + best)) pending = false;
                     win.s_prev = win.s_to;
-                    reach *= 4;
+                    reach *= RT_HIER_GROWTH;
                 }
                 every_sphere = overflowed;
             }

@@ -12,8 +12,8 @@
 //
 // The top list is the same for all lanes and is read through the scalar unit; below it every lane
 // follows its own survivors.  Clusters and candidates go to two short per-lane lists in LDS; a lane
-// whose lists overflow reports that, and the caller screens all spheres for it (the plain loop
-// over the whole table).
+// whose candidate list overflows reports that, and the caller screens all spheres for it (the
+// plain loop over the whole table).
 #pragma once
 #include <math.h>
 
@@ -142,8 +142,28 @@ __device__ __forceinline__ int hier_candidates(const Dev& D, LaneList B, LaneLis
         }
         if (!active) m = 0;
         // 2. every lane takes its own surviving entries one by one: the clusters of a block that
-        //    survive go to the lane's cluster list, a loose sphere is a candidate already
+        //    survive go to the lane's cluster list, a loose sphere is a candidate already.  When
+        //    some lane's cluster list is nearly full, the wave works the lists off (step 3).
         int nB = 0;
+        auto clusters_to_spheres = [&]() {
+            // 3. the spheres of the listed clusters (as many steps as the longest list of the wave)
+            for (int i = 0; __ballot(i < nB) != 0; ++i) {
+                if (i < nB) {
+                    const uint32_t cl = B[i];
+                    const Group8Regs g = load_group(D.hier_leaf, cl);
+                    const uint4 ids = reinterpret_cast<const uint4*>(D.hier_ids)[cl];   // 8 sphere indices of 16 bits
+                    const uint32_t id2[4] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const CullRange r = cull_range(g.pair(0, k), g.pair(1, k), g.pair(2, k), g.pair(3, k), ox, oy, oz, dx, dy, dz, e_ray, win.s_from);
+                        const uint32_t s0 = id2[k] & 0xffffu, s1 = id2[k] >> 16;
+                        if (keep(r, 0) && s0 != HIER_NO_SPHERE) push(s0);
+                        if (keep(r, 1) && s1 != HIER_NO_SPHERE) push(s1);
+                    }
+                }
+            }
+            nB = 0;
+        };
         while (__ballot(m != 0) != 0) {
             if (m != 0) {
                 const int e = __builtin_ctzll(m);
@@ -162,29 +182,13 @@ __device__ __forceinline__ int hier_candidates(const Dev& D, LaneList B, LaneLis
                         const CullRange r = cull_range(g.pair(0, k), g.pair(1, k), g.pair(2, k), g.pair(3, k), ox, oy, oz, dx, dy, dz, e_ray, win.s_from);
 #pragma unroll
                         for (int w = 0; w < 2; ++w)
-                            if (keep(r, w)) {
-                                if (nB < HIER_CAP) B[nB++] = (uint16_t)(ref * 8 + 2 * k + w); else overflow = true;
-                            }
+                            if (keep(r, w)) B[nB++] = (uint16_t)(ref * 8 + 2 * k + w);   // room for 8 is kept free
                     }
                 }
             }
+            if (__ballot(nB > HIER_CAP - 8) != 0) clusters_to_spheres();
         }
-        // 3. the spheres of the listed clusters (as many steps as the longest list of the wave)
-        for (int i = 0; __ballot(i < nB) != 0; ++i) {
-            if (i < nB) {
-                const uint32_t cl = B[i];
-                const Group8Regs g = load_group(D.hier_leaf, cl);
-                const uint4 ids = reinterpret_cast<const uint4*>(D.hier_ids)[cl];   // 8 sphere indices of 16 bits
-                const uint32_t id2[4] = {ids.x, ids.y, ids.z, ids.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const CullRange r = cull_range(g.pair(0, k), g.pair(1, k), g.pair(2, k), g.pair(3, k), ox, oy, oz, dx, dy, dz, e_ray, win.s_from);
-                    const uint32_t s0 = id2[k] & 0xffffu, s1 = id2[k] >> 16;
-                    if (keep(r, 0) && s0 != HIER_NO_SPHERE) push(s0);
-                    if (keep(r, 1) && s1 != HIER_NO_SPHERE) push(s1);
-                }
-            }
-        }
+        clusters_to_spheres();
     }
     if (overflow) return -1;
     // 3. ascending sphere order (the list is short: insertion sort)
