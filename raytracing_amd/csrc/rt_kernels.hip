@@ -30,6 +30,9 @@
 #ifndef RT_TRACE_WAVES_MANY
 #define RT_TRACE_WAVES_MANY 4   // the same for the many-sphere variant of k_trace
 #endif
+#ifndef RT_SURFACE_WAVES_MANY
+#define RT_SURFACE_WAVES_MANY 2   // waves per SIMD requested for the many-sphere variant of k_surface
+#endif
 #ifndef RT_HIER_GROWTH
 #define RT_HIER_GROWTH 4    // each stretch of a ray searched in the sphere hierarchy is this many times the one before
 #endif

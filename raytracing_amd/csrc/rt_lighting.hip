@@ -454,7 +454,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
 // ---------------------------------------------------------------------------------------------
 // Lighting for the dense list of hits whose surface colour matters (all levels).
 template <bool LDS, bool MIXED, bool SIMPLE = false>
-__global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : 2) void k_surface(Dev D) {
+__global__ __launch_bounds__(BLOCK, MIXED ? RT_MIXED_WAVES : (LDS ? 2 : RT_SURFACE_WAVES_MANY)) void k_surface(Dev D) {
     constexpr int TABLE = MIXED ? SREG : (LDS ? SHADE_LDS_SPHERES : 1);   // the float32 pass is for S <= SREG
     __shared__ ShadowSphere s_sh[TABLE];
     __shared__ SurfaceMaterial s_mat[TABLE];
