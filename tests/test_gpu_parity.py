@@ -569,3 +569,15 @@ def test_benchmark_size_properties(name):
             part.ctx.shade()
             strip = part.ctx.read_image().reshape(100, W, 3)
         assert np.array_equal(strip, img[1000:1100])
+
+
+@pytest.mark.gpu
+def test_hierarchy_matches_plain_screening_at_full_size():
+    """The 4096-sphere scene at 3840x2160 (482 M rays): with and without the hierarchy the frame is
+    bit for bit the same."""
+    from raytracing_amd.flatten import flatten_scene
+    flat = flatten_scene(synthetic.many_spheres_scene(4096, 3840, 2160))
+    out = _with_and_without_hierarchy(flat, 3840, 2160)
+    assert out["1"][1:] == out["0"][1:]
+    assert out["1"][1] == 482_185_288 and out["1"][2] == 376_397_367      # as measured when the scene was first rendered
+    assert np.array_equal(out["1"][0], out["0"][0])
