@@ -75,7 +75,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _watchdog(seconds=240):
+    """A worker that is still alive after this long dumps its stacks and exits: a rank stuck in an
+    exchange must not outlive the test and keep the GPU (or the port) busy."""
+    import faulthandler
+    faulthandler.dump_traceback_later(seconds, exit=True)
+
+
 def _worker(rank, world, port, kind, w, h, seed, out_path):
+    _watchdog()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -138,6 +146,7 @@ def test_two_ranks_spotlight_in_beam_ranks(tmp_path):
 
 
 def _worker_rgb8(rank, world, port, name, w, h, out_path):
+    _watchdog()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -23,7 +23,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _watchdog(seconds=240):
+    """A worker that is still alive after this long dumps its stacks and exits: a rank stuck in an
+    exchange must not outlive the test and keep the GPU (or the port) busy."""
+    import faulthandler
+    faulthandler.dump_traceback_later(seconds, exit=True)
+
+
 def _worker(rank, world, port, name, w, h, out_path):
+    _watchdog()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -74,6 +82,7 @@ def test_two_ranks_on_one_gpu(tmp_path, name, tol):
 
 
 def _worker_rgb8(rank, world, port, name, w, h, out_path):
+    _watchdog()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -109,6 +118,7 @@ SET_SCENES = ["example_2", "example_4", "example_3"]
 
 
 def _worker_frame_set(rank, world, port, w, h, out_path, env):
+    _watchdog()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.update(env)
