@@ -24,7 +24,11 @@ Two timed regions of K steps each, both bracketed by barrier + synchronize:
    overlap, from which `kernel_ms_per_step` and the rooflines are computed
    (`ms_per_step_frames_sequential` is this region's wall time per step).
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every
+With --gpus N > 1 there is one rank (process) per GPU: either started by
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or,
+when WORLD_SIZE is not set, by this script itself - the parent starts N fresh child
+processes with those variables set before it has touched the GPU or torch, relays their
+output, and exits non-zero if any of them does.  Every
 frame is split into N contiguous row blocks of equal estimated cost; after
 every bounce level one all-reduce sums the per-node batch sizes of all four
 frames (the small-batch rule needs whole-image sizes); the float64 image tiles
@@ -95,6 +99,67 @@ def measured_traffic(kernel, args, world):
     return None
 
 
+def spawn_ranks(n, argv):
+    """Start ``n`` fresh processes of this script, one rank per GPU, and wait for them.  The parent
+    never imports torch or touches the GPU.  Rank 0 prints the JSON line (the children inherit
+    stdout).  If a rank fails, the others (stuck in a collective without it) are ended, and its
+    exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for rank in sorted(pending):
+            code = procs[rank].poll()
+            if code is None:
+                continue
+            pending.discard(rank)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {rank} exited with code {code}; stopping the other ranks", file=sys.stderr)
+        if rc != 0:
+            for rank in pending:
+                procs[rank].terminate()
+            for rank in pending:
+                try:
+                    procs[rank].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[rank].kill()
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def rendezvous_only(world):
+    """--rendezvous-only: form the process group, sum the ranks, print a JSON line.  Exercises the
+    launch path (self-started ranks or torch.distributed.run) without a GPU."""
+    from raytracing_amd.distributed import init_group
+    rank, world_seen, group = init_group(world)
+    total = rank
+    if world_seen > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([rank], dtype=torch.int64)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.all_reduce(t, group=group)
+        total = int(t.item())
+        dist.barrier(group=group)
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world_seen, "rank_sum": total}))
+    if world_seen > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,7 +173,19 @@ def main():
     ap.add_argument("--frames", choices=["overlapped", "sequential"], default="overlapped",
                     help="sequential: region 1 also runs the frames one after the other (profiler runs, "
                          "so that kernel durations are free of overlap)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="only start the ranks and form the process group (no GPU work): checks the launch path")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks")
+    if args.rendezvous_only:
+        return rendezvous_only(args.gpus)
 
     if os.environ.get("RT_BENCH_WATCHDOG"):     # dump every thread's stack and exit if the run stalls
         import faulthandler
@@ -120,6 +197,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if "RT_BENCH_DEVICE" in os.environ:      # rehearsal of several ranks on one GPU
         local_rank = int(os.environ["RT_BENCH_DEVICE"])
+    from raytracing_amd import _native
+    if local_rank >= _native.device_count():
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but only {_native.device_count()} are visible "
+                 f"(--gpus {args.gpus})")
     torch.cuda.set_device(local_rank)
     W, H = args.width, args.height
 

@@ -245,14 +245,15 @@ int rt_upload_samples(RtContext *ctx, int64_t dst_offset, const double *u, int64
  * among them (rt_set_sample_layout_global, after rt_set_sample_layout; `total` = length of
  * the whole stream).  Every context then generates the whole stream and keeps its columns,
  * and all of them return the same final state. */
-/* Host only: the coefficients (bit i = coefficient of x^i, 624 words) of x^(2^k) mod the
- * characteristic polynomial of MT19937's one-word step - the jump-ahead polynomials
- * rt_generate_samples uses to start its parallel streams.  0 <= k < 48. */
-int rt_mt19937_jump_poly(int32_t k, uint32_t *out624);
 int rt_set_sample_layout_global(RtContext *ctx, const int64_t *offsets, const int64_t *columns,
                                 const int64_t *first_column /* each [n_nodes][RT_MAX_LIGHTS] */, int64_t total);
 int rt_generate_samples(RtContext *ctx, const uint32_t *key /* [624] */, int32_t pos,
                         uint32_t *key_out /* [624] */, int32_t *pos_out);
+
+/* Host only: the coefficients (bit i = coefficient of x^i, 624 words) of x^(2^k) mod the
+ * characteristic polynomial of MT19937's one-word step - the jump-ahead polynomials
+ * rt_generate_samples uses to start its parallel streams.  0 <= k < 48. */
+int rt_mt19937_jump_poly(int32_t k, uint32_t *out624);
 
 /* Arithmetic of the disk-light sample loop in rt_shade.
  * RT_PRECISION_F64: every sample in float64, the reference's operations.
@@ -267,7 +268,8 @@ int rt_set_precision(RtContext *ctx, int32_t mode);
 /* Lighting, shading and bottom-up colour combination (reference
  * raytrace.py:135-170 and objects.py:94-235), deepest level first.  Leaves the
  * clipped pixel colours (reference raytrace.py:15) on the device.  Does not
- * synchronise. */
+ * synchronise.  With disk lights in the scene: RT_ERR_STATE unless the whole sample stream
+ * announced by rt_set_sample_layout has been uploaded or generated. */
 int rt_shade(RtContext *ctx);
 
 /* Optional: have rt_shade write the colours into caller-owned DEVICE memory

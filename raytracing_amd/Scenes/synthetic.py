@@ -5,7 +5,17 @@
 * :func:`many_spheres_scene` - one huge ground sphere plus ``n_spheres - 1``
   small random spheres, 70 % of them glass (intersection bound).
 
-Both are built only from the reference's public classes' parameters, so the
+* :func:`tir_scene` - camera inside a glass sphere, a sphere of refractive index
+  below 1 and two overlapping glass spheres: thousands of rays take the total
+  internal reflection branch (reference raytrace.py:122-127).
+* :func:`clip_scene` - a sphere of refractive index 0.8 with strong absorption over
+  a mirror-like ground: transmitted rays that leave the surface almost tangentially
+  miss the sphere they "entered", the reference's path length is then -1 and its
+  attenuation factor exceeds 1 (reference raytrace.py:117-120), so the per-call clip
+  (reference raytrace.py:170) changes colours below the top level.  Meant to be
+  rendered with ``EPSILON = 1e-2`` (the band of such rays is 2 EPSILON / radius wide).
+
+All are built only from the reference's public classes' parameters, so the
 same generator run against the reference's classes yields the same scene; the
 golden images under ``tests/golden`` were produced that way.
 """
@@ -82,3 +92,53 @@ def many_spheres_scene(n_spheres=4096, width=None, height=None,
                              **cam_kwargs)
     ambient = _objects.AmbientLight(intensity=1 / 10, color=WHITE)
     return _scene_cls(spheres, lights, camera, camera.screen, ambient)
+
+
+def _camera(_objects, width, height, **kwargs):
+    if _objects is objects:
+        kwargs.update(pixels_x=width, pixels_y=height)
+    return _objects.Camera(**kwargs)
+
+
+def tir_scene(width=None, height=None, _objects=objects, _materials=materials, _scene_cls=Scene):
+    """Scene whose rays often meet a surface beyond the critical angle."""
+    M = _materials.Material
+    ground = _objects.Sphere(x=0, y=0, z=-1000000, radius=1000000,
+                             material=M(diffuse_color=WHITE, reflection_coefficient=0, smoothness=0.3))
+    # the camera at (0, 1, 4) sits 1.44 from the centre of this sphere of radius 2 and index 1.5:
+    # sideways rays meet the wall at up to asin(0.72), beyond the critical angle asin(1 / 1.5)
+    bubble = _objects.Sphere(x=1.2, y=1, z=3.2, radius=2.0,
+                             material=M(diffuse_color=WHITE, transparency_coefficient=0.95, refractive_index=1.5,
+                                        smoothness=0.3, attenuation_coefficient=0.05))
+    # index below 1: rays from outside with cos(incidence) < 0.6 are totally reflected on entry
+    thin = _objects.Sphere(x=5, y=-0.5, z=1, radius=1.0,
+                           material=M(diffuse_color=RED, transparency_coefficient=0.9, refractive_index=0.8,
+                                      smoothness=0.5))
+    # overlapping glass: a ray inside one sphere meets the other's surface at any angle
+    left = _objects.Sphere(x=5, y=2, z=1.0, radius=0.8,
+                           material=M(diffuse_color=GREEN, transparency_coefficient=0.9, refractive_index=1.5,
+                                      smoothness=0.6))
+    right = _objects.Sphere(x=5.6, y=2.4, z=1.2, radius=0.8,
+                            material=M(diffuse_color=BLUE, transparency_coefficient=0.8, refractive_index=1.3,
+                                       smoothness=0.4, reflection_coefficient=0.1))
+    lights = [_objects.PointSource(4, 0, 8, intensity=60)]
+    camera = _camera(_objects, width, height, x=0, y=1, z=4)
+    ambient = _objects.AmbientLight(intensity=1 / 10, color=WHITE)
+    return _scene_cls([ground, bubble, thin, left, right], lights, camera, camera.screen, ambient)
+
+
+def clip_scene(width=None, height=None, _objects=objects, _materials=materials, _scene_cls=Scene):
+    """Scene in which the reference's attenuation factor exceeds 1 (see the module docstring)."""
+    M = _materials.Material
+    ground = _objects.Sphere(x=0, y=0, z=-1000000, radius=1000000,
+                             material=M(diffuse_color=GREY, reflection_coefficient=0.6, smoothness=0.8))
+    ball = _objects.Sphere(x=4, y=1, z=1.6, radius=1.5,
+                           material=M(diffuse_color=WHITE, transparency_coefficient=0.9, refractive_index=0.8,
+                                      smoothness=0.2, attenuation_coefficient=3.0))
+    small = _objects.Sphere(x=3, y=-1.2, z=0.5, radius=0.5,
+                            material=M(diffuse_color=YELLOW, transparency_coefficient=0.7, refractive_index=0.9,
+                                       smoothness=0.1, attenuation_coefficient=2.0))
+    lights = [_objects.PointSource(4, 0, 6, intensity=25)]
+    camera = _camera(_objects, width, height, x=0, y=1, z=4)
+    ambient = _objects.AmbientLight(intensity=1 / 10, color=WHITE)
+    return _scene_cls([ground, ball, small], lights, camera, camera.screen, ambient)

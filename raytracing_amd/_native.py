@@ -152,6 +152,11 @@ def _vec3(dst, src):
         dst[i] = float(src[i])
 
 
+def device_count():
+    """GPUs visible to the HIP runtime (0 when there is none)."""
+    return int(load_library().rt_device_count())
+
+
 def mt19937_jump_poly(k):
     """Coefficient words of x^(2^k) mod MT19937's characteristic polynomial (host computation)."""
     out = np.empty(624, dtype=np.uint32)

@@ -153,6 +153,7 @@ struct RtContext {
     bool explicit_xy = false;
     int64_t arena_rays = 0;
     int64_t sample_total = 0;
+    int64_t samples_delivered = 0;   // values uploaded or generated since the layout was set
 
     int precision = RT_PRECISION_MIXED;
     bool profiling = false;
@@ -229,16 +230,16 @@ int use_device(RtContext* ctx) {
 
 // Dynamic LDS of the bookkeeping kernels: the per-node tables of one level.
 size_t level_table_bytes(RtContext* ctx, int level) {
-    static const bool raised = [] {
-        // levels wider than ~680 nodes need more than the default 64 KiB of dynamic LDS
-        const int most = MAX_LEVEL_NODES * LEVEL_TABLE_BYTES;
-        bool ok = hipFuncSetAttribute((const void*)k_link, hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
-        ok &= hipFuncSetAttribute((const void*)k_combine<true>, hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
-        ok &= hipFuncSetAttribute((const void*)k_combine<false>, hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
-        return ok;
-    }();
-    (void)raised;
     return (size_t)(ctx->tree.level_start[level + 1] - ctx->tree.level_start[level]) * LEVEL_TABLE_BYTES;
+}
+
+// Levels wider than ~680 nodes need more than the default 64 KiB of dynamic LDS.  The limit is a
+// property of the kernel on the current device, so every context raises it on its own device.
+hipError_t raise_dynamic_lds_limit() {
+    const int most = MAX_LEVEL_NODES * LEVEL_TABLE_BYTES;
+    if (hipError_t e = hipFuncSetAttribute((const void*)k_link, hipFuncAttributeMaxDynamicSharedMemorySize, most)) return e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)k_combine<true>, hipFuncAttributeMaxDynamicSharedMemorySize, most)) return e;
+    return hipFuncSetAttribute((const void*)k_combine<false>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
 }
 
 int launch_level(RtContext* ctx, int level) {
@@ -312,6 +313,7 @@ int rt_create(int32_t device, void* stream, RtContext** out) {
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device %d out of range (%d visible)", device, n);
     HIP_TRY(hipSetDevice(device));
+    HIP_TRY(raise_dynamic_lds_limit());
     RtContext* ctx = new RtContext();
     ctx->device = device;
     if (stream) {
@@ -662,6 +664,7 @@ int rt_set_sample_layout(RtContext* ctx, const int64_t* offsets, int64_t total) 
     HIP_TRY(hipMemcpy(ctx->sample_off.p, offsets, n * sizeof(int64_t), hipMemcpyHostToDevice));
     ctx->pack_E = entries;
     ctx->sample_total = total;
+    ctx->samples_delivered = 0;
     ctx->layout_set = true;
     ctx->have_global_layout = false;
     return RT_OK;
@@ -700,6 +703,7 @@ int rt_upload_samples(RtContext* ctx, int64_t dst_offset, const double* u, int64
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller
+    ctx->samples_delivered += n;
     return RT_OK;
 }
 
@@ -710,6 +714,7 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     if (pos < 0 || pos > MT_N) return fail(RT_ERR_INVALID, "MT19937 position %d out of range", pos);
     // doubles to draw (two 32-bit outputs each): the whole image's stream
     const long long total = ctx->have_global_layout ? ctx->global_total : ctx->sample_total;
+    ctx->samples_delivered = ctx->sample_total;   // the whole stream of this context is made below
     if (total == 0) {
         memcpy(key_out, key, MT_N * sizeof(uint32_t));
         *pos_out = pos;
@@ -804,6 +809,9 @@ int rt_shade(RtContext* ctx) {
     if (!ctx->geometry_done) return fail(RT_ERR_STATE, "geometry phase not finished");
     if (ctx->sampled_lights && !ctx->layout_set)
         return fail(RT_ERR_STATE, "the scene has disk lights: upload their samples before shading");
+    if (ctx->sampled_lights && ctx->samples_delivered < ctx->sample_total)
+        return fail(RT_ERR_STATE, "only %lld of the %lld disk-light sample values have been uploaded or generated",
+                    (long long)ctx->samples_delivered, (long long)ctx->sample_total);
     const Dev D = ctx->dev();
     const bool lds = ctx->S <= SHADE_LDS_SPHERES;
     const bool mixed = ctx->precision == RT_PRECISION_MIXED && ctx->sampled_lights && ctx->S <= SREG && ctx->have_packed32;

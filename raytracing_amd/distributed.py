@@ -260,6 +260,11 @@ class ShardedRenderer:
         return rows, cost
 
     def choose_rows(self):
+        if self.comm.world > self.params.height:
+            # a rank without rows would still have to take part in every exchange with zero counts;
+            # not supported: every rank raises here, before any collective, so none is left waiting
+            raise ValueError(f"{self.comm.world} ranks for an image of {self.params.height} rows: "
+                             "every rank needs at least one row")
         if self.comm.world == 1:
             self.bounds = np.array([0, self.params.height], dtype=np.int64)
         else:
@@ -287,10 +292,13 @@ class ShardedRenderer:
     # ---- phases --------------------------------------------------------------------------
     def begin(self, output_ptr=None):
         r0, r1 = self.my_rows
-        n = max(r1 - r0, 0)
+        n = r1 - r0
+        if n < 1:
+            raise RuntimeError(f"rank {self.comm.rank} has no rows (bounds {self.bounds.tolist()}): choose_rows() gives "
+                               "every rank at least one")
         if not self.arena_rays:
-            self.arena_rays = self.rays_per_pixel * max(n, 1) * self.params.width
-        self.ctx.begin_rows(r0, max(n, 1) if n == 0 else n, self.params.width, self.arena_rays)
+            self.arena_rays = self.rays_per_pixel * n * self.params.width
+        self.ctx.begin_rows(r0, n, self.params.width, self.arena_rays)
         if output_ptr:
             self.ctx.set_output(output_ptr)
 

@@ -180,3 +180,26 @@ def test_frame_set_one_gpu_graph_matches_plain_issue():
     for name, a, b in zip(SET_SCENES, plain, replayed):
         assert np.array_equal(a, b)
         assert np.abs(b - g[name + "_image"]).max() <= (2e-5 if name == "example_4" else 1e-8)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment: the script starts both ranks (here
+    on the one GPU of the box, gloo carrying the exchanges) and rank 0 reports n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RT_DIST_BACKEND="gloo", RT_BENCH_DEVICE="0", RT_BENCH_WATCHDOG="200")
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--width", "160", "--height", "90", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    g = np.load(os.path.join(GOLDEN, "images_160x90.npz"))
+    want = sum(int(g[n + "_rays"][g[n + "_rays"] >= 3].sum()) for n in ("example_1", "example_2", "example_3", "example_4"))
+    assert out["config"]["rays_per_step"] == want
