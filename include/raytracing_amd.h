@@ -300,6 +300,26 @@ int rt_get_counters(RtContext *ctx, RtCounters *out);
 int rt_profile_enable(RtContext *ctx, int32_t on);
 int rt_get_profile(RtContext *ctx, RtProfile *out, int32_t reset);
 
+/* Test hook: evaluate, on the GPU, one of the device functions the frame kernels are built from
+ * for n caller-supplied input rows (host arrays, row-major doubles; synchronises).  Uses the scene
+ * of the last rt_set_scene.  Rows in -> out:
+ *   RT_DEBUG_SPHERE_ROOTS  o[3] d[3] sphere -> closest t, furthest t (-1: none)
+ *                          reference objects.py:60-66 Sphere.intersection, :238-271 solve_quadratic
+ *   RT_DEBUG_NEAREST       o[3] d[3] -> sphere (-1: miss), t (inf: miss); at most 64 spheres
+ *                          reference objects.py:288-299 find_closest_intersected_object
+ *   RT_DEBUG_SHADOW        o[3] d[3] -> RGB multiplier; at most 128 spheres
+ *                          reference objects.py:274-285 shadow_objects_multipliers
+ *   RT_DEBUG_OPTICS        N[3] d[3] n1 n2 -> T[3], transmitted (0/1), R, mirror direction[3]
+ *                          reference raytrace.py:198-212 refract_vectors, :173-189 fresnel_multiplier
+ *                          (R = 1 for totally reflected rays, raytrace.py:99), :192-195 reflect_vectors
+ *   RT_DEBUG_EASE          mode x a d -> factor
+ *                          reference objects.py:176-191 ease_fall_off_beam, :302-338
+ *   RT_DEBUG_SCREEN        X Y -> screen point[3], unit ray direction[3]
+ *                          reference objects.py:45-51 index_to_position, raytrace.py:7-10 */
+enum { RT_DEBUG_SPHERE_ROOTS = 0, RT_DEBUG_NEAREST = 1, RT_DEBUG_SHADOW = 2, RT_DEBUG_OPTICS = 3, RT_DEBUG_EASE = 4,
+       RT_DEBUG_SCREEN = 5 };
+int rt_debug_eval(RtContext *ctx, int32_t what, const double *in, double *out, int64_t n);
+
 /* Convenience: rt_begin_frame(whole image) + geometry + shade + read, for
  * scenes without disk lights (no samples needed). */
 int rt_render(RtContext *ctx, double *out_rgb);

@@ -145,9 +145,16 @@ class Oracle:
         return _roots(B, C, furthest)
 
     def _sphere_roots(self, sid, o, d, furthest):
-        """Per-ray root against the ray's own sphere ``sid``."""
+        """Per-ray root against the ray's own sphere ``sid``.  The product of direction and
+        centre is taken per sphere with ``np.dot`` on that sphere's rows, as the reference's
+        ``Sphere.intersection`` does (reference objects.py:62): BLAS sums in another order than
+        ``np.sum``, which shows in the last bits for the ground spheres."""
         c = self.centers[sid]
-        B = 2 * (_dot(d, o) - _dot(d, c))
+        d_c = np.empty(d.shape[0])
+        for i in np.unique(sid):
+            rows = sid == i
+            d_c[rows] = np.dot(d[rows], self.centers[i])
+        B = 2 * (_dot(d, o) - d_c)
         diff = c - o
         C = _dot(diff, diff) - self.radii[sid] ** 2
         return _roots(B, C, furthest)

@@ -108,6 +108,7 @@ SIGNATURES = {
     "rt_profile_enable": (C.c_int, [_P, C.c_int32]),
     "rt_get_profile": (C.c_int, [_P, C.POINTER(RtProfile), C.c_int32]),
     "rt_render": (C.c_int, [_P, _F64P]),
+    "rt_debug_eval": (C.c_int, [_P, C.c_int32, _F64P, _F64P, C.c_int64]),
 }
 
 _lib = None
@@ -385,6 +386,18 @@ class Context:
         p = RtProfile()
         _check(self.lib.rt_get_profile(self._h, C.byref(p), 1 if reset else 0))
         return {k: {"ms": p.ms[i], "launches": p.launches[i]} for i, k in enumerate(KERNEL_KINDS)}
+
+    DEBUG_FUNCTIONS = {"sphere_roots": (0, 7, 2), "nearest": (1, 6, 2), "shadow": (2, 6, 3), "optics": (3, 8, 8),
+                       "ease": (4, 4, 1), "screen": (5, 2, 6)}
+
+    def debug_eval(self, what, rows):
+        """Evaluate one of the kernels' device functions for the given input rows (see
+        rt_debug_eval in the header); returns the output rows."""
+        code, in_w, out_w = self.DEBUG_FUNCTIONS[what]
+        rows = _f64(rows).reshape(-1, in_w)
+        out = np.empty((rows.shape[0], out_w), dtype=np.float64)
+        _check(self.lib.rt_debug_eval(self._h, code, _ptr(rows, C.c_double), _ptr(out, C.c_double), rows.shape[0]))
+        return out
 
     def render(self, height, width):
         out = np.empty((int(height) * int(width), 3), dtype=np.float64)

@@ -979,6 +979,38 @@ int rt_get_profile(RtContext* ctx, RtProfile* out, int32_t reset) {
     return RT_OK;
 }
 
+int rt_debug_eval(RtContext* ctx, int32_t what, const double* in, double* out, int64_t n) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->have_scene) return fail(RT_ERR_STATE, "rt_set_scene has not been called");
+    static const int widths[][2] = {{7, 2}, {6, 2}, {6, 3}, {8, 8}, {4, 1}, {2, 6}};   // per RT_DEBUG_*: in, out
+    if (what < 0 || what > RT_DEBUG_SCREEN) return fail(RT_ERR_INVALID, "unknown debug function %d", what);
+    if (n < 0 || (n > 0 && (!in || !out))) return fail(RT_ERR_INVALID, "bad debug arguments");
+    if (what == RT_DEBUG_NEAREST && ctx->S > SPH_CHUNK_SMALL) return fail(RT_ERR_INVALID, "RT_DEBUG_NEAREST takes at most %d spheres", SPH_CHUNK_SMALL);
+    if (what == RT_DEBUG_SHADOW && ctx->S > SHADE_LDS_SPHERES) return fail(RT_ERR_INVALID, "RT_DEBUG_SHADOW takes at most %d spheres", SHADE_LDS_SPHERES);
+    if (n == 0) return RT_OK;
+    const int in_w = widths[what][0], out_w = widths[what][1];
+    if (what == RT_DEBUG_SPHERE_ROOTS)
+        for (int64_t i = 0; i < n; ++i) {
+            const double sph = in[i * in_w + 6];
+            if (!(sph >= 0 && sph < ctx->S && sph == (double)(int)sph)) return fail(RT_ERR_INVALID, "row %lld: sphere index out of range", (long long)i);
+        }
+    DevBuf<double> d_in, d_out;
+    HIP_TRY(d_in.ensure((size_t)n * in_w));
+    hipError_t e = d_out.ensure((size_t)n * out_w);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in.p, in, (size_t)n * in_w * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + BLOCK - 1) / BLOCK, NB));
+        hipLaunchKernelGGL(k_debug, dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(), (int)what, d_in.p, in_w, d_out.p, out_w, (long long)n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out.p, (size_t)n * out_w * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    d_in.release();
+    d_out.release();
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_debug_eval: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 int rt_render(RtContext* ctx, double* out_rgb) {
     if (int rc = use_device(ctx)) return rc;
     if (!ctx->have_scene) return fail(RT_ERR_STATE, "rt_set_scene has not been called");

@@ -56,6 +56,64 @@ __global__ void k_init(Dev D) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pieces of k_trace that are also callable on their own (rt_debug_eval checks them against
+// vectors recorded from the reference's functions).
+
+// Primary ray of pixel (X, Y) (reference objects.py:45-51 and raytrace.py:7-12): point on the
+// screen and unit direction from the camera.
+__device__ __forceinline__ V3 screen_point(const SceneConst& sc, double X, double Y) {
+    const double sx = X * sc.scr_w / sc.pix_x - sc.scr_w / 2;
+    const double sy = (sc.pix_y - Y) * sc.scr_h / sc.pix_y - sc.scr_h / 2;
+    return sx * ld3(sc.scr_x) + sy * ld3(sc.scr_y) + ld3(sc.scr_pos);
+}
+
+// Nearest positive root over a sphere table [S][4] = centre, radius^2 (reference objects.py:288-299):
+// the float64 test for every sphere, two per iteration (two independent dependency chains in
+// flight); ties go to the later sphere, as the reference's min_t == t update does.
+__device__ __forceinline__ void nearest_of_table(const double (*sph)[4], int S, V3 o, V3 d, double d_o, double& best, int& sid) {
+    auto test = [&](int i) {
+        double lo, hi;
+        const bool h = sphere_roots(o, d, d_o, sph[i][0], sph[i][1], sph[i][2], sph[i][3], lo, hi);
+        return h ? (lo > 0 ? lo : hi) : -1.0;
+    };
+    int i = 0;
+    for (; i + 1 < S; i += 2) {
+        const double t0 = test(i), t1 = test(i + 1);
+        if (t0 > 0 && t0 <= best) { best = t0; sid = i; }
+        if (t1 > 0 && t1 <= best) { best = t1; sid = i + 1; }
+    }
+    if (i < S) {
+        const double t0 = test(i);
+        if (t0 > 0 && t0 <= best) { best = t0; sid = i; }
+    }
+}
+
+// Refraction and Fresnel reflectance at a hit (reference raytrace.py:92-99, :173-212).  N faces
+// along the ray (d.N >= 0), mu = n1 / n2, r0 = ((n1 - n2) / (n1 + n2))^2.
+struct Optics {
+    bool trans;   // a transmitted ray exists (no total internal reflection)
+    double kq;    // 1 - mu^2 (1 - cos^2): squared length of the transmitted vector along N
+    V3 T;         // transmitted direction (zero when !trans)
+    double R;     // reflectance: Schlick's approximation, 1 under total internal reflection
+};
+__device__ __forceinline__ double refraction_discriminant(double mu, double cosi) { return 1 - mu * mu * (1 - cosi * cosi); }
+__device__ __forceinline__ Optics hit_optics(V3 N, V3 d, double cosi, double mu, double r0, bool n2_ge_n1) {
+    Optics o;
+    o.kq = refraction_discriminant(mu, cosi);
+    o.trans = o.kq >= 0;
+    o.T = {0, 0, 0};
+    if (o.trans) o.T = xsqrt(o.kq) * N + mu * (d - cosi * N);   // reference raytrace.py:207-211
+    const double cosf = n2_ge_n1 ? cosi : dot(o.T, N);
+    const double om = 1 - cosf;
+    const double om2 = om * om;
+    o.R = r0 + (1 - r0) * (om2 * om2 * om);
+    if (!o.trans) o.R = 1;
+    return o;
+}
+// Mirror direction about the surface (reference raytrace.py:192-195 with the normal -N).
+__device__ __forceinline__ V3 mirror_direction(V3 d, V3 N, double cosi) { return d - cosi * (2.0 * N); }
+
+// ---------------------------------------------------------------------------------------------
 // Nearest hit + hit record for one level.  Every wave walks its own run of tiles.  All the
 // small tables a tile needs (the level's nodes, the scene constants and, with few spheres,
 // the sphere constants) are staged in LDS once per workgroup, so that the only vector-memory
@@ -200,9 +258,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                 const int i = first + lane;
                 if (D.X) { X = D.X[i]; Y = D.Y[i]; }
                 else { X = (double)(i % sc.width); Y = (double)(D.row0 + i / sc.width); }
-                double sx = X * sc.scr_w / sc.pix_x - sc.scr_w / 2;
-                double sy = (sc.pix_y - Y) * sc.scr_h / sc.pix_y - sc.scr_h / 2;
-                V3 pix = sx * ld3(sc.scr_x) + sy * ld3(sc.scr_y) + ld3(sc.scr_pos);
+                const V3 pix = screen_point(sc, X, Y);
                 o = ld3(sc.cam);
                 d = normalize(pix - o);
             } else {
@@ -227,7 +283,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                 } else {
                     // mirror direction about the surface (reference raytrace.py:192-195);
                     // total internal reflection and plain reflection share it
-                    d = pd - cosi * (2.0 * sf.N);
+                    d = mirror_direction(pd, sf.N, cosi);
                     o = sf.Pb;
                     live = (br == 1) ? (pinfo & I_LIVE_TI) : (pinfo & I_LIVE_R);
                 }
@@ -327,26 +383,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                 flush();
             }
         }
-        if (SMALL && active) {
-            // few spheres, all in LDS: the float64 test for every one, two per iteration (two
-            // independent dependency chains in flight); ties go to the later sphere, as the
-            // reference's min_t == t update does
-            auto test = [&](int i) {
-                double lo, hi;
-                const bool h = sphere_roots(o, d, d_o, s_sph[i][0], s_sph[i][1], s_sph[i][2], s_sph[i][3], lo, hi);
-                return h ? (lo > 0 ? lo : hi) : -1.0;
-            };
-            int i = 0;
-            for (; i + 1 < S; i += 2) {
-                const double t0 = test(i), t1 = test(i + 1);
-                if (t0 > 0 && t0 <= best) { best = t0; sid = i; }
-                if (t1 > 0 && t1 <= best) { best = t1; sid = i + 1; }
-            }
-            if (i < S) {
-                const double t0 = test(i);
-                if (t0 > 0 && t0 <= best) { best = t0; sid = i; }
-            }
-        }
+        if (SMALL && active) nearest_of_table(s_sph, S, o, d, d_o, best, sid);   // few spheres, all in LDS
         if (!tile_ok) return;
 
         // ---- hit record (reference raytrace.py:53-101) -------------------------------------
@@ -363,22 +400,16 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
             V3 Pb = P - eps * N;
             const double mu = inside ? sr.mu_in : sr.mu_out;   // n1 / n2
             const double cosi = dot(N, d);
-            const double kq = 1 - mu * mu * (1 - cosi * cosi);
-            const bool trans = kq >= 0;
+            const bool trans = refraction_discriminant(mu, cosi) >= 0;
             // Reflected fraction and path length inside the sphere only matter for a ray whose
             // colour reaches the pixel (the others are traced for the batch and hit counts only).
             double A = 0, through = 0;
             if (live) {
-                V3 T = {0, 0, 0};
-                if (trans) T = xsqrt(kq) * N + mu * (d - cosi * N);  // reference raytrace.py:207-211
-                const double r0 = sr.r0;   // ((n1 - n2) / (n1 + n2))^2, the same value from either side
-                const double cosf = (n2 >= n1) ? cosi : dot(T, N);
-                const double om = 1 - cosf;
-                const double om2 = om * om;
-                double R = r0 + (1 - r0) * (om2 * om2 * om);
-                if (!trans) R = 1;
+                // sr.r0 = ((n1 - n2) / (n1 + n2))^2 is the same value from either side
+                const Optics op = hit_optics(N, d, cosi, mu, sr.r0, n2 >= n1);
+                const V3 T = op.T;
                 const double floor_ = inside ? 0.0 : sr.floor_;
-                A = floor_ + (sr.refl_max - floor_) * R;
+                A = floor_ + (sr.refl_max - floor_) * op.R;
                 if (b != 0 && trans && !inside) {
                     // distance to the far side of the entered sphere (reference raytrace.py:117-118)
                     double lo, hi;

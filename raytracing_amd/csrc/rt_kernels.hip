@@ -46,3 +46,4 @@
 #include "rt_samples.hip"
 #include "rt_lighting.hip"
 #include "rt_image.hip"
+#include "rt_debug.hip"

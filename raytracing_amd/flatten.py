@@ -110,6 +110,11 @@ def _flatten_light(light):
         raise ValueError("a disk light needs at least one sample point")
     disk = dict(radius=float(light.radius), n_points=n_points, normal=normal,
                 x_hat=x_hat, y_hat=y_hat)
+    # A disk light evaluates its samples through a fresh PointSource(intensity / n_points), whose
+    # colours are always white (reference objects.py:140-144): the disk light's own colour
+    # attributes never reach the image.
+    common["diffuse_color"] = np.ones(3)
+    common["specular_color"] = np.ones(3)
     if hasattr(light, "angle") and hasattr(light, "easing_mode"):
         fall_off = float(getattr(light, "fall_off_angle", 20 * np.pi / 180))
         # An unknown easing string leaves the factor at one, like "none"

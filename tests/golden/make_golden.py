@@ -18,6 +18,7 @@ nothing in them, and records inputs and outputs only:
 * ``unit_kats.npz``     function-level input/output vectors
 * ``rgb8.npz``          the 8-bit images the reference's output step (``plt.imsave``, main.py:32)
                         writes: example_1-3 at 1000x1000, example_4 at 500x500 (seed 0)
+* ``disk_colour_48x27.npz``  example_4 with and without colours set on its disk light
 * ``tir_160x90.npz``    scene with thousands of rays in the total-internal-reflection branch
 * ``clip_160x90.npz``   scene (EPSILON = 1e-2) where the attenuation factor exceeds 1 and the
                         per-call clip of raytrace.py:170 is active below the top level; the largest
@@ -358,6 +359,19 @@ def gen_rgb8(ref_dir):
     save("rgb8.npz", **out)
 
 
+def gen_disk_colour(ref_dir):
+    """A DiskSource whose colour attributes are set: the reference ignores them (its samples go
+    through a fresh white PointSource, objects.py:140-144)."""
+    ref = Ref(ref_dir, 48, 27)
+    scene = ref.scenes["example_4"]
+    plain = ref.render(scene, seed=0)
+    scene.light_sources[0].diffuse_color = np.array([1.0, 0.0, 0.0])
+    scene.light_sources[0].specular_color = np.array([0.0, 0.0, 1.0])
+    coloured = ref.render(scene, seed=0)
+    print("disk colour: max difference", np.abs(plain - coloured).max(), flush=True)
+    save("disk_colour_48x27.npz", plain=plain, coloured=coloured)
+
+
 class ClipSpy:
     """Stands in for the ``np`` name inside the reference's raytrace module: every attribute is
     NumPy's, except that ``clip`` also records, per recursion depth, the largest value handed to
@@ -439,7 +453,7 @@ GENERATORS = {
     "scenes_flat": gen_scenes_flat, "images": gen_images, "depths": gen_depths, "spot": gen_spot,
     "many_257": lambda r: gen_many(r, 257), "many_4096": lambda r: gen_many(r, 4096),
     "strips": gen_strips, "traces_500": gen_traces_500, "unit": gen_unit, "rgb8": gen_rgb8,
-    "tir": gen_tir, "clip": gen_clip, "full_1080": gen_full_1080, "full_4k": gen_full_4k,
+    "disk_colour": gen_disk_colour, "tir": gen_tir, "clip": gen_clip, "full_1080": gen_full_1080, "full_4k": gen_full_4k,
 }
 
 if __name__ == "__main__":
