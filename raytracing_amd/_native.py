@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "_rt_hip.so")
 RT_MAX_LIGHTS = 8
 RT_MAT_WIDTH = 18
 RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_OVERFLOW, RT_ERR_STATE = 0, -1, -2, -3, -4
+NOALLOC_MAX_SAMPLES = 1 << 20
 KERNEL_KINDS = ("trace", "scan", "link", "surface", "combine", "init")
 
 
@@ -91,6 +92,7 @@ SIGNATURES = {
     "rt_get_node_counts": (C.c_int, [_P, _I64P, _I64P, _I64P]),
     "rt_set_sample_layout": (C.c_int, [_P, _I64P, C.c_int64]),
     "rt_upload_samples": (C.c_int, [_P, C.c_int64, _F64P, C.c_int64]),
+    "rt_upload_samples_noalloc": (C.c_int, [_P, C.c_int64, _F64P, C.c_int64]),
     "rt_build_hierarchy": (C.c_int, [_F64P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint16),
                                      C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "rt_mt19937_jump_poly": (C.c_int, [C.c_int32, C.POINTER(C.c_uint32)]),
@@ -319,6 +321,11 @@ class Context:
     def upload_samples(self, dst_offset, u):
         u = _f64(u).reshape(-1)
         _check(self.lib.rt_upload_samples(self._h, int(dst_offset), _ptr(u, C.c_double), u.size))
+
+    def upload_samples_noalloc(self, dst_offset, u):
+        """upload_samples without any device allocation; at most NOALLOC_MAX_SAMPLES values per call."""
+        u = _f64(u).reshape(-1)
+        _check(self.lib.rt_upload_samples_noalloc(self._h, int(dst_offset), _ptr(u, C.c_double), u.size))
 
     def set_sample_layout_global(self, offsets, columns, first_column, total):
         """Where this context's columns sit in the whole image's stream (see the header)."""

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -15,9 +16,34 @@
 
 using namespace rt;
 
+// Staging memory of rt_upload_samples_noalloc: one array per GPU, part of the loaded code object,
+// so using it needs no allocation.  Host code must not use the array's name as an address (it is a
+// host-side stand-in): upload_scratch_of() asks the runtime for the array's device address, once
+// per device with that device current, and everything else uses that pointer.
+static __device__ __align__(256) double g_upload_scratch[RT_NOALLOC_MAX_SAMPLES];
+
 namespace {
 
 thread_local std::string g_error;
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+double* g_scratch_ptr[MAX_DEVICES] = {nullptr};
+
+// Device address of g_upload_scratch on `device`, which must be the current device.
+hipError_t upload_scratch_of(int device, double** out) {
+    *out = nullptr;
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_upload_scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = (double*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -154,6 +180,7 @@ struct RtContext {
     int64_t arena_rays = 0;
     int64_t sample_total = 0;
     int64_t samples_delivered = 0;   // values uploaded or generated since the layout was set
+    double* upload_scratch = nullptr;   // this GPU's g_upload_scratch (see upload_scratch_of)
 
     int precision = RT_PRECISION_MIXED;
     bool profiling = false;
@@ -314,8 +341,11 @@ int rt_create(int32_t device, void* stream, RtContext** out) {
     if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device %d out of range (%d visible)", device, n);
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(raise_dynamic_lds_limit());
+    double* scratch = nullptr;
+    HIP_TRY(upload_scratch_of(device, &scratch));
     RtContext* ctx = new RtContext();
     ctx->device = device;
+    ctx->upload_scratch = scratch;
     if (stream) {
         ctx->stream = (hipStream_t)stream;
     } else {
@@ -703,6 +733,32 @@ int rt_upload_samples(RtContext* ctx, int64_t dst_offset, const double* u, int64
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller
+    ctx->samples_delivered += n;
+    return RT_OK;
+}
+
+int rt_upload_samples_noalloc(RtContext* ctx, int64_t dst_offset, const double* u, int64_t n) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->layout_set) return fail(RT_ERR_STATE, "rt_set_sample_layout has not been called");
+    if (n < 0 || dst_offset < 0 || dst_offset + n > ctx->sample_total) return fail(RT_ERR_INVALID, "sample range out of bounds");
+    if (n > (int64_t)RT_NOALLOC_MAX_SAMPLES)
+        return fail(RT_ERR_INVALID, "rt_upload_samples_noalloc takes at most %lld values per call (got %lld): split the stream",
+                    (long long)RT_NOALLOC_MAX_SAMPLES, (long long)n);
+    if (n == 0) return RT_OK;
+    if (!u) return fail(RT_ERR_INVALID, "u is null");
+    // The staging array is shared by every call on this GPU and still holds the previous piece:
+    // k_pack reads chunk[0 .. n) only, so nothing has to be cleared, but this context's previous
+    // scatter must have finished reading before the array is overwritten.
+    double* const staging = ctx->upload_scratch;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyAsync(staging, u, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->pack_E > 0) {
+        const int64_t blocks = std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB);
+        hipLaunchKernelGGL((k_pack<UploadedStream>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(),
+                           UploadedStream{staging}, dst_offset, n);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller, the array by the next call
     ctx->samples_delivered += n;
     return RT_OK;
 }
