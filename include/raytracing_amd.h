@@ -28,7 +28,7 @@ extern "C" {
 #define RT_MAX_LIGHTS 8
 #define RT_MAX_SPHERES 65535
 #define RT_MAT_WIDTH 18
-#define RT_NUM_COUNTERS (7 + RT_MAX_LIGHTS)
+#define RT_NUM_COUNTERS (8 + RT_MAX_LIGHTS)
 
 #define RT_OK 0
 #define RT_ERR_INVALID (-1)   /* bad argument / unsupported scene            */

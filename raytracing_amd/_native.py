@@ -12,7 +12,8 @@ import numpy as np
 from . import flatten as F
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_rt_hip.so")
+# RT_HIP_LIB: another build of the same library (kernel experiments side by side on one GPU box)
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "_rt_hip.so")
 
 RT_MAX_LIGHTS = 8
 RT_MAT_WIDTH = 18

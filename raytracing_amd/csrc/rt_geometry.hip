@@ -701,58 +701,73 @@ __global__ __launch_bounds__(BLOCK) void k_link(Dev D, int level) {
         wave_base = D.blk_tot[((size_t)level * NCNT + lane) * NB + blockIdx.x] + D.wave_off[((size_t)level * NCNT + lane) * NW + wid];
     __syncthreads();
     int kk = (t_begin < t_end) ? find_node(T.node, nn, t_begin) : 0;
-    for (int t0 = t_begin; t0 < t_end; t0 += UNROLL_TILES) {
+    struct Loaded {                      // what a group of UNROLL_TILES tiles needs from memory
         int kn[UNROLL_TILES];            // node of the tile, relative to the level
         uint32_t info[UNROLL_TILES];
         unsigned trun[UNROLL_TILES];     // lane c: counter c at the tile's start, relative to the wave's
-        // phase A: the loads of all tiles of this iteration
+    };
+    // requests the info words and counters of the tiles t0 .. t0 + UNROLL_TILES - 1
+    auto fetch = [&](int t0, Loaded& g) {
 #pragma unroll
         for (int u = 0; u < UNROLL_TILES; ++u) {
             const int t = t0 + u;
-            info[u] = I_NO_HIT;
-            kn[u] = 0;
-            trun[u] = 0;
+            g.info[u] = I_NO_HIT;
+            g.kn[u] = 0;
+            g.trun[u] = 0;
             if (t < t_end) {
                 while (T.node[kk].tile_end <= t) ++kk;
                 kk = __builtin_amdgcn_readfirstlane(kk);
-                kn[u] = kk;
+                g.kn[u] = kk;
                 const NodeRec r = T.node[kk];
                 const int first = (t - __builtin_amdgcn_readfirstlane(r.tile0)) * TILE;
                 const int cnt = min(TILE, __builtin_amdgcn_readfirstlane(r.n) - first);
-                if (lane < cnt) info[u] = D.info[(uint32_t)(tbase + t) * TILE + lane];
-                if (lane < NCNT) trun[u] = D.tile_run[(size_t)(tbase + t) * NCNT + lane];
+                if (lane < cnt) g.info[u] = D.info[(uint32_t)(tbase + t) * TILE + lane];
+                if (lane < NCNT) g.trun[u] = D.tile_run[(size_t)(tbase + t) * NCNT + lane];
             }
         }
-        // phase B: ranks and stores
+    };
+    // ranks and stores of one group
+    auto emit = [&](int t0, const Loaded& g) {
 #pragma unroll
         for (int u = 0; u < UNROLL_TILES; ++u) {
             const int t = t0 + u;
             if (t >= t_end) break;
             const uint32_t idx = (uint32_t)(tbase + t) * TILE + lane;
+            const uint32_t in = g.info[u];
             // lane c: rank offset of counter c inside the node (inside the level for the shading list)
-            const int base = (int)(wave_base + trun[u] - T.pre[kn[u] * 16 + (lane & 15)]);
+            const int base = (int)(wave_base + g.trun[u] - T.pre[g.kn[u] * 16 + (lane & 15)]);
             int rank[NCNT];
 #pragma unroll
             for (int c = 0; c < NCNT; ++c) {
                 rank[c] = 0;
-                if ((want >> c) & 1u) rank[c] = lanes_below(__ballot(counted(info[u], c))) + LANE(base, c);
+                if ((want >> c) & 1u) rank[c] = lanes_below(__ballot(counted(in, c))) + LANE(base, c);
             }
             if (has_children) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    if ((info[u] >> (18 + c)) & 1u) D.link[T.child[kn[u] * 4 + c] + rank[c]] = idx;
+                    if ((in >> (18 + c)) & 1u) D.link[T.child[g.kn[u] * 4 + c] + rank[c]] = idx;
                 }
             }
-            if (info[u] & I_SHADE) {
+            if (in & I_SHADE) {
                 const int e = shade_base + rank[C_SHADE];
                 D.list_ray[e] = idx;
-                D.list_node[e] = (uint16_t)(k0 + kn[u]);
+                D.list_node[e] = (uint16_t)(k0 + g.kn[u]);
                 if (D.list_j[0]) D.list_j[0][e] = (uint32_t)rank[C_HIT];
 #pragma unroll
                 for (int l = 0; l < RT_MAX_LIGHTS; ++l)
                     if ((D.spot_mask >> l) & 1u) D.list_j[1 + l][e] = (uint32_t)rank[C_BEAM0 + l];
             }
         }
+    };
+    // Two groups in turn, each with its own registers: the loads of the next group are requested
+    // before the current group's ranks and stores, and no register with a load in flight is copied.
+    Loaded ga, gb;
+    fetch(t_begin, ga);
+    for (int t0 = t_begin; t0 < t_end; t0 += 2 * UNROLL_TILES) {
+        fetch(t0 + UNROLL_TILES, gb);
+        emit(t0, ga);
+        fetch(t0 + 2 * UNROLL_TILES, ga);
+        emit(t0 + UNROLL_TILES, gb);
     }
 }
 

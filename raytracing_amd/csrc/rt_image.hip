@@ -7,11 +7,22 @@ namespace rt {
 // ---------------------------------------------------------------------------------------------
 // Bottom-up colour combination for one level (reference raytrace.py:155-170); the
 // deepest level runs first.  A ray's colour replaces its surface colour in place.
-// Two tiles per loop iteration; per iteration the loads come in two sets (the info words
-// and counters, then everything the info words select), each set issued together.
+//
+// Only rays whose colour reaches the pixel ("live") have anything to combine, and in most
+// scenes most tiles hold none (every ray below an opaque, non-reflecting hit is traced for the
+// batch and hit counts only).  A wave therefore first reads the running count of live hits that
+// k_trace left at each of its tiles and visits only the tiles where it changes.  The tiles it
+// visits go through a two-stage software pipeline, two tiles per stage: while the colours one
+// pair selected are in flight, the info words of the next pair are requested already.
 constexpr int COMBINE_TILES = 2;
 struct CombineSphere {
     double tr, kr, kg, kb;   // transparency, -attenuation * absorption colour
+};
+struct CombineTile {   // first stage of the pipeline: what is known / requested about a tile
+    int t;             // tile (relative to the level), -1: none
+    int kn, first;     // node of the tile (relative to the level), index of its first ray in the node
+    uint32_t info;
+    unsigned trun;     // lanes 0-2: running child counts at the tile's start
 };
 template <bool SMALL>   // SMALL: at most SPH_CHUNK_SMALL spheres, their constants in LDS
 __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
@@ -41,45 +52,67 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
         wave_base = D.blk_tot[((size_t)level * NCNT + lane) * NB + blockIdx.x] + D.wave_off[((size_t)level * NCNT + lane) * NW + wid];
     __syncthreads();
 
-    int kk = (t_begin < t_end) ? find_node(T.node, nn, t_begin) : 0;
-    for (int t0 = t_begin; t0 < t_end; t0 += COMBINE_TILES) {
-        int kn[COMBINE_TILES], first[COMBINE_TILES];
-        uint32_t info[COMBINE_TILES];
-        unsigned trun[COMBINE_TILES];
-        // first set of loads: info words and the running child counts of the tiles
-#pragma unroll
-        for (int u = 0; u < COMBINE_TILES; ++u) {
-            const int t = t0 + u;
-            info[u] = I_NO_HIT;
-            kn[u] = 0; first[u] = 0; trun[u] = 0;
+    // ---- which tiles to visit ---------------------------------------------------------------
+    // A live ray that misses everything still needs the background colour stored for its parent,
+    // so the count that matters is that of live rays of either kind (column C_ANYLIVE).
+    int chunk0 = t_begin;                      // first tile of the current chunk of 64 tiles
+    unsigned long long todo = 0;               // tiles of the chunk still to visit
+    auto next_chunk = [&]() {
+        while (todo == 0 && chunk0 < t_end) {
+            const int t = chunk0 + lane;
+            bool visit = false;
             if (t < t_end) {
-                while (T.node[kk].tile_end <= t) ++kk;
-                kk = __builtin_amdgcn_readfirstlane(kk);
-                kn[u] = kk;
-                const NodeRec r = T.node[kk];
-                first[u] = (t - __builtin_amdgcn_readfirstlane(r.tile0)) * TILE;
-                const int cnt = min(TILE, __builtin_amdgcn_readfirstlane(r.n) - first[u]);
-                if (lane < cnt) info[u] = D.info[(uint32_t)(tbase + t) * TILE + lane];
-                if (has_children && lane < 3) trun[u] = D.tile_run[(size_t)(tbase + t) * NCNT + lane];
+                const unsigned here = D.tile_run[(size_t)(tbase + t) * NCNT + C_ANYLIVE];
+                // the running count is local to the wave that traced these tiles (the wave with this
+                // index): the next tile's value tells this tile's count; the last tile is always visited
+                visit = t + 1 >= t_end || D.tile_run[(size_t)(tbase + t + 1) * NCNT + C_ANYLIVE] != here;
             }
+            todo = __ballot(visit);
+            if (todo == 0) chunk0 += 64;
         }
-        // second set of loads: what the info words select
+    };
+    int kk = (t_begin < t_end) ? find_node(T.node, nn, t_begin) : 0;
+    auto fetch = [&]() -> CombineTile {   // takes the next tile to visit and requests its info words
+        CombineTile c;
+        c.t = -1; c.kn = 0; c.first = 0; c.info = I_NO_HIT; c.trun = 0;
+        next_chunk();
+        if (todo != 0) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int t = chunk0 + j;
+            if (todo == 0) chunk0 += 64;
+            c.t = t;
+            while (T.node[kk].tile_end <= t) ++kk;
+            kk = __builtin_amdgcn_readfirstlane(kk);
+            c.kn = kk;
+            const NodeRec r = T.node[kk];
+            c.first = (t - __builtin_amdgcn_readfirstlane(r.tile0)) * TILE;
+            const int cnt = min(TILE, __builtin_amdgcn_readfirstlane(r.n) - c.first);
+            if (lane < cnt) c.info = D.info[(uint32_t)(tbase + t) * TILE + lane];
+            if (has_children && lane < 3) c.trun = D.tile_run[(size_t)(tbase + t) * NCNT + lane];
+        }
+        return c;
+    };
+
+    // One pipeline step: second set of loads for the pair `cur`, then the first set of the pair
+    // after it (into `nxt`), then arithmetic and stores for `cur`.
+    auto step = [&](const CombineTile (&cur)[COMBINE_TILES], CombineTile (&nxt)[COMBINE_TILES]) {
         double A[COMBINE_TILES], through[COMBINE_TILES];
         V3 surf[COMBINE_TILES], refr[COMBINE_TILES], refl[COMBINE_TILES];
 #pragma unroll
         for (int u = 0; u < COMBINE_TILES; ++u) {
-            const uint32_t idx = (uint32_t)(tbase + t0 + u) * TILE + lane;
-            const uint32_t in = info[u];
+            const uint32_t idx = (uint32_t)(tbase + max(cur[u].t, 0)) * TILE + lane;
+            const uint32_t in = cur[u].info;
             A[u] = 0; through[u] = 0;
             surf[u] = {0, 0, 0}; refr[u] = {0, 0, 0}; refl[u] = {0, 0, 0};
             const bool want_ti = (in & I_LIVE_TI) && (in & (I_CHILD_T | I_CHILD_I));
             const bool want_r = (in & I_LIVE_R) && (in & I_CHILD_R);
             uint32_t slot[3] = {0, 0, 0};   // arena index of the ray's child of each kind
             if (has_children && __ballot(want_ti || want_r) != 0) {
-                const int base = (int)(wave_base + trun[u] - T.pre[kn[u] * 16 + (lane & 15)]);
+                const int base = (int)(wave_base + cur[u].trun - T.pre[cur[u].kn * 16 + (lane & 15)]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    slot[c] = T.child[kn[u] * 4 + c] + LANE(base, c) + lanes_below(__ballot(((in >> (18 + c)) & 1u) != 0));
+                    slot[c] = T.child[cur[u].kn * 4 + c] + LANE(base, c) + lanes_below(__ballot(((in >> (18 + c)) & 1u) != 0));
             }
             if ((in & I_LIVE) && is_hit(in)) {
                 A[u] = D.A[idx];
@@ -95,11 +128,14 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < COMBINE_TILES; ++u) nxt[u] = fetch();
         // arithmetic and stores
 #pragma unroll
         for (int u = 0; u < COMBINE_TILES; ++u) {
-            const uint32_t idx = (uint32_t)(tbase + t0 + u) * TILE + lane;
-            const uint32_t in = info[u];
+            if (cur[u].t < 0) continue;
+            const uint32_t idx = (uint32_t)(tbase + cur[u].t) * TILE + lane;
+            const uint32_t in = cur[u].info;
             if (in & I_LIVE) {   // nobody reads the colour of a ray whose weight in the pixel is zero
                 V3 col = bg;
                 if (is_hit(in)) {
@@ -115,13 +151,23 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
                     col = clip01(((1 - cs.tr) * (1 - A[u])) * surf[u] + (cs.tr * (1 - A[u])) * rf + A[u] * refl[u]);
                 }
                 if (level == 0) {   // a primary ray's colour is the pixel; no parent reads it
-                    double* out = D.image + (size_t)(first[u] + lane) * 3;
+                    double* out = D.image + (size_t)(cur[u].first + lane) * 3;
                     out[0] = col.x; out[1] = col.y; out[2] = col.z;
                 } else {
                     D.cr[idx] = col.x; D.cg[idx] = col.y; D.cb[idx] = col.z;
                 }
             }
         }
+    };
+
+    // two register sets, so that no register with a load in flight is ever copied
+    CombineTile pa[COMBINE_TILES], pb[COMBINE_TILES];
+#pragma unroll
+    for (int u = 0; u < COMBINE_TILES; ++u) pa[u] = fetch();
+    while (pa[0].t >= 0) {
+        step(pa, pb);
+        if (pb[0].t < 0) break;
+        step(pb, pa);
     }
 }
 

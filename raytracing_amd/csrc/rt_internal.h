@@ -22,7 +22,8 @@ constexpr int SHADE_LDS_SPHERES = 128; // sphere and material tables of the ligh
 // counters
 enum { C_T = 0, C_I = 1, C_R = 2, C_HIT = 3, C_BEAM0 = 4, C_SHADE = 4 + RT_MAX_LIGHTS,
        C_REC = 5 + RT_MAX_LIGHTS,    // hits whose record (hit point, direction) is stored
-       C_LIVE = 6 + RT_MAX_LIGHTS }; // hits with non-zero weight in the pixel
+       C_LIVE = 6 + RT_MAX_LIGHTS,   // hits with non-zero weight in the pixel
+       C_ANYLIVE = 7 + RT_MAX_LIGHTS }; // rays (hits and misses) with non-zero weight in the pixel
 
 // bits of the per-ray info word
 constexpr uint32_t I_SID_MASK = 0xFFFFu;   // sphere hit, I_NO_HIT for a miss

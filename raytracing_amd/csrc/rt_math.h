@@ -137,6 +137,7 @@ __device__ __forceinline__ bool counted(uint32_t info, int c) {
     if (c == C_HIT) return is_hit(info);
     if (c == C_REC) return is_hit(info) && (info & (I_CHILD_T | I_CHILD_I | I_CHILD_R | I_SHADE)) != 0;
     if (c == C_LIVE) return is_hit(info) && (info & I_LIVE) != 0;
+    if (c == C_ANYLIVE) return (info & I_LIVE) != 0;
     const int bit = c < 3 ? 18 + c : (c == C_SHADE ? 21 : I_BEAM_SHIFT + (c - C_BEAM0));
     return (info >> bit) & 1u;
 }

@@ -445,8 +445,8 @@ def gen_full_1080(ref_dir, names=("example_1", "example_2", "example_3", "exampl
     _gen_full(ref_dir, 1920, 1080, names, 30, 32, "full_1080.npz")
 
 
-def gen_full_4k(ref_dir):
-    _gen_full(ref_dir, 3840, 2160, ("example_1", "example_2", "example_3"), 60, 64, "full_4k.npz")
+def gen_full_4k(ref_dir, names=("example_1", "example_2", "example_3")):
+    _gen_full(ref_dir, 3840, 2160, names, 60, 64, "full_4k.npz")
 
 
 GENERATORS = {
