@@ -110,7 +110,7 @@ typedef struct RtCounters {
     int64_t shaded_hits;     /* hits whose surface colour was evaluated by rt_shade (hits
                                 with zero weight in the pixel are skipped)             */
     int64_t shaded_samples;  /* light samples evaluated for them = shadow rays cast    */
-    int64_t fallback_samples;/* disk-light samples the float32 evaluation could not
+    int64_t fallback_samples;/* light samples of the hits the float32 evaluation could not
                                 certify and re-evaluated in float64 (mixed precision)  */
     int64_t stored_records;  /* hits whose record (hit point, direction) was stored: hits
                                 with a child ray or a surface colour that matters      */
@@ -120,7 +120,8 @@ typedef struct RtCounters {
     int32_t n_nodes;         /* nodes of the static ray tree                           */
     int32_t n_levels;        /* bounce levels (longest path + 1)                       */
     int32_t overflow;        /* non-zero: arena too small, results invalid             */
-    int32_t reserved;
+    int32_t certify_mismatches; /* RT_PRECISION_MIXED_CHECKED only: certified float32 shadow
+                                decisions that differ from the float64 decision (must be 0) */
 } RtCounters;
 
 /* Accumulated device time per kernel kind, filled when profiling is on. */
@@ -272,8 +273,11 @@ int rt_mt19937_jump_poly(int32_t k, uint32_t *out624);
  * every shadow-ray discriminant; a sample with a decision inside its bound is
  * re-evaluated in float64, so shadow decisions are those of the float64 path and
  * colours differ by float32 rounding of continuous terms only (< 1e-5).
- * Geometry (hits, child rays, counts) is float64 in both modes. */
-enum { RT_PRECISION_F64 = 0, RT_PRECISION_MIXED = 1 };
+ * The float32 pass takes scenes of up to 64 spheres; larger ones are evaluated in float64.
+ * RT_PRECISION_MIXED_CHECKED (tests): as MIXED, and every certified decision is compared
+ * with the float64 decision on the device; RtCounters.certify_mismatches counts differences.
+ * Geometry (hits, child rays, counts) is float64 in all modes. */
+enum { RT_PRECISION_F64 = 0, RT_PRECISION_MIXED = 1, RT_PRECISION_MIXED_CHECKED = 2 };
 int rt_set_precision(RtContext *ctx, int32_t mode);
 
 /* Lighting, shading and bottom-up colour combination (reference

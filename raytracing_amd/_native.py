@@ -63,7 +63,7 @@ class RtCounters(C.Structure):
                 ("shaded_hits", C.c_int64), ("shaded_samples", C.c_int64), ("fallback_samples", C.c_int64),
                 ("stored_records", C.c_int64), ("live_hits", C.c_int64),
                 ("arena_rays_used", C.c_int64), ("arena_capacity", C.c_int64),
-                ("n_nodes", C.c_int32), ("n_levels", C.c_int32), ("overflow", C.c_int32), ("reserved", C.c_int32)]
+                ("n_nodes", C.c_int32), ("n_levels", C.c_int32), ("overflow", C.c_int32), ("certify_mismatches", C.c_int32)]
 
 
 class RtProfile(C.Structure):
@@ -117,6 +117,24 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels carry their own copy of the HIP runtime (torch/lib/libamdhip64.so, same
+    SONAME as the system's).  One process must use one copy: with two, whichever initialises second
+    finds no GPU, and streams or device pointers of one mean nothing to the other.  If torch is
+    installed, its copy is loaded first (without importing torch), so this library and a later
+    ``import torch`` resolve to the same runtime; without torch the system's runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Load (once) and return the shared library, with prototypes attached."""
     global _lib
@@ -127,6 +145,7 @@ def load_library():
             f"{LIB_PATH} is missing: the HIP extension has not been built. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` in the repository root "
             "(needs hipcc; no CPU fallback exists).")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
@@ -350,8 +369,8 @@ class Context:
         return key_out, int(pos_out.value)
 
     def set_precision(self, mode):
-        """"f64" or "mixed" (see rt_set_precision in the header)."""
-        _check(self.lib.rt_set_precision(self._h, {"f64": 0, "mixed": 1}[mode]))
+        """"f64", "mixed" or "mixed_checked" (see rt_set_precision in the header)."""
+        _check(self.lib.rt_set_precision(self._h, {"f64": 0, "mixed": 1, "mixed_checked": 2}[mode]))
 
     def shade(self):
         _check(self.lib.rt_shade(self._h))

@@ -153,7 +153,9 @@ struct RtContext {
     DevBuf<double> X, Y, packed, staging, image;
     DevBuf<float> packed32;
     bool have_packed32 = false;
-    bool simple_shading = false;   // see disk_light_mixed: coefficients in [0, 1], lights with one colour
+    bool disk_points_ready = false;   // packed32 holds the disk points of the current contents of packed
+    int64_t pack32_base[RT_MAX_LIGHTS] = {0};
+    bool simple_shading = false;   // see SampleSums in rt_lighting_mixed.hip: coefficients in [0, 1], grey lights
     int64_t pack_base[RT_MAX_LIGHTS] = {0};
     int64_t pack_E = 0;
     DevBuf<int64_t> sample_off, sample_global;
@@ -208,7 +210,7 @@ struct RtContext {
         D.X = explicit_xy ? X.p : nullptr; D.Y = explicit_xy ? Y.p : nullptr;
         D.row0 = row0; D.npix = (int32_t)npix;
         D.packed = packed.p; D.packed32 = have_packed32 ? packed32.p : nullptr; D.pack_E = pack_E; D.sample_off = sample_off.p; D.sample_global = have_global_layout ? sample_global.p : nullptr;
-        for (int l = 0; l < RT_MAX_LIGHTS; ++l) D.pack_base[l] = pack_base[l];
+        for (int l = 0; l < RT_MAX_LIGHTS; ++l) { D.pack_base[l] = pack_base[l]; D.pack32_base[l] = pack32_base[l]; }
         D.image = user_image ? user_image : image.p;
         return D;
     }
@@ -412,6 +414,23 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
             if (L.kind == RT_LIGHT_SPOT) spot_mask |= 1u << l; else disk = true;
         }
         sc.lights[l] = L;
+        if (L.kind != RT_LIGHT_POINT) {
+            LightF32& F = sc.lightf[l];
+            for (int k = 0; k < 3; ++k) {
+                F.xh[k] = (float)(L.radius * L.x_hat[k]);
+                F.yh[k] = (float)(L.radius * L.y_hat[k]);
+                F.dcol[k] = (float)L.diffuse_color[k];
+                F.scol[k] = (float)L.specular_color[k];
+            }
+            F.ps = (float)(L.intensity / L.n_points);
+            F.ps_grey = (float)(L.intensity / L.n_points * L.diffuse_color[0]);
+            // |radius (x x_hat + y y_hat)| over the unit disk is at most radius times the largest
+            // singular value of the frame (x_hat, y_hat), whatever the frame
+            const double a = L.x_hat[0] * L.x_hat[0] + L.x_hat[1] * L.x_hat[1] + L.x_hat[2] * L.x_hat[2];
+            const double c = L.y_hat[0] * L.y_hat[0] + L.y_hat[1] * L.y_hat[1] + L.y_hat[2] * L.y_hat[2];
+            const double b = L.x_hat[0] * L.y_hat[0] + L.x_hat[1] * L.y_hat[1] + L.x_hat[2] * L.y_hat[2];
+            F.extent = (float)(fabs(L.radius) * sqrt(0.5 * (a + c + sqrt((a - c) * (a - c) + 4 * b * b))) * 1.000001);
+        }
     }
     memcpy(sc.ambient, scene->ambient, 24);
     memcpy(sc.cam, scene->camera_position, 24);
@@ -521,9 +540,13 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
             const double k = scene->sphere_mat[i * RT_MAT_WIDTH + c];
             if (!(k >= 0.0 && k <= 1.0)) simple = false;
         }
-    for (int l = 0; l < scene->n_lights && simple; ++l)
-        if (scene->lights[l].kind != RT_LIGHT_POINT && memcmp(scene->lights[l].diffuse_color, scene->lights[l].specular_color, 24) != 0)
-            simple = false;
+    for (int l = 0; l < scene->n_lights && simple; ++l) {
+        const RtLight& L = scene->lights[l];
+        if (L.kind == RT_LIGHT_POINT) continue;
+        if (memcmp(L.diffuse_color, L.specular_color, 24) != 0) simple = false;
+        if (!(L.diffuse_color[0] == L.diffuse_color[1] && L.diffuse_color[0] == L.diffuse_color[2] && L.diffuse_color[0] >= 0)) simple = false;
+        if (!(L.intensity >= 0)) simple = false;
+    }
     ctx->simple_shading = simple;
 
     ctx->tree = std::move(tree);
@@ -688,9 +711,18 @@ int rt_set_sample_layout(RtContext* ctx, const int64_t* offsets, int64_t total) 
         if (ctx->sc_host.lights[l].kind != RT_LIGHT_POINT) slots += (int64_t)ctx->sc_host.lights[l].n_points * entries;
     }
     HIP_TRY(ctx->packed.ensure((size_t)slots * 2));
-    // scenes the float32 sample pass can take also keep the pairs rounded to float
-    ctx->have_packed32 = ctx->S <= SREG;
-    if (ctx->have_packed32) HIP_TRY(ctx->packed32.ensure((size_t)slots * 2));
+    // scenes the float32 sample pass can take also keep the samples' disk points as floats (Dev::packed32)
+    ctx->have_packed32 = ctx->S <= MIXED_MAX_SPHERES;
+    if (ctx->have_packed32) {
+        const int64_t tiles = ((int64_t)entries + TILE - 1) / TILE;
+        int64_t quads = 0;
+        for (int l = 0; l < ctx->sc_host.n_lights; ++l) {
+            ctx->pack32_base[l] = quads;
+            if (ctx->sc_host.lights[l].kind != RT_LIGHT_POINT) quads += tiles * ((ctx->sc_host.lights[l].n_points + 1) / 2) * TILE;
+        }
+        HIP_TRY(ctx->packed32.ensure((size_t)quads * 4));
+    }
+    ctx->disk_points_ready = false;
     HIP_TRY(hipMemcpy(ctx->sample_off.p, offsets, n * sizeof(int64_t), hipMemcpyHostToDevice));
     ctx->pack_E = entries;
     ctx->sample_total = total;
@@ -734,6 +766,7 @@ int rt_upload_samples(RtContext* ctx, int64_t dst_offset, const double* u, int64
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller
     ctx->samples_delivered += n;
+    ctx->disk_points_ready = false;
     return RT_OK;
 }
 
@@ -760,6 +793,7 @@ int rt_upload_samples_noalloc(RtContext* ctx, int64_t dst_offset, const double* 
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller, the array by the next call
     ctx->samples_delivered += n;
+    ctx->disk_points_ready = false;
     return RT_OK;
 }
 
@@ -771,6 +805,7 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     // doubles to draw (two 32-bit outputs each): the whole image's stream
     const long long total = ctx->have_global_layout ? ctx->global_total : ctx->sample_total;
     ctx->samples_delivered = ctx->sample_total;   // the whole stream of this context is made below
+    ctx->disk_points_ready = false;
     if (total == 0) {
         memcpy(key_out, key, MT_N * sizeof(uint32_t));
         *pos_out = pos;
@@ -870,12 +905,27 @@ int rt_shade(RtContext* ctx) {
                     (long long)ctx->samples_delivered, (long long)ctx->sample_total);
     const Dev D = ctx->dev();
     const bool lds = ctx->S <= SHADE_LDS_SPHERES;
-    const bool mixed = ctx->precision == RT_PRECISION_MIXED && ctx->sampled_lights && ctx->S <= SREG && ctx->have_packed32;
+    const bool mixed = ctx->precision != RT_PRECISION_F64 && ctx->sampled_lights && ctx->S <= MIXED_MAX_SPHERES && ctx->have_packed32;
+    const bool check = ctx->precision == RT_PRECISION_MIXED_CHECKED;
+    if (mixed && !ctx->disk_points_ready) {
+        // once per sample stream (not per frame): the float32 pass reads disk points, see k_disk_points
+        for (int l = 0; l < ctx->sc_host.n_lights && ctx->pack_E > 0; ++l) {
+            const RtLight& L = ctx->sc_host.lights[l];
+            if (L.kind == RT_LIGHT_POINT) continue;
+            const int64_t n = ((ctx->pack_E + TILE - 1) / TILE) * ((L.n_points + 1) / 2) * TILE;
+            const int64_t blocks = std::min<int64_t>((n + BLOCK - 1) / BLOCK, 16 * NB);
+            hipLaunchKernelGGL(k_disk_points, dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->packed.p + 2 * ctx->pack_base[l],
+                               ctx->pack_E, L.n_points, reinterpret_cast<float4*>(ctx->packed32.p) + ctx->pack32_base[l]);
+        }
+        ctx->disk_points_ready = true;
+    }
     ctx->begin(RT_K_SURFACE);
-    if (lds && mixed && ctx->simple_shading) hipLaunchKernelGGL((k_surface<true, true, true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
-    else if (lds && mixed) hipLaunchKernelGGL((k_surface<true, true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
-    else if (lds) hipLaunchKernelGGL((k_surface<true, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
-    else hipLaunchKernelGGL((k_surface<false, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    if (mixed && check && ctx->simple_shading) hipLaunchKernelGGL((k_surface_mixed<true, true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    else if (mixed && check) hipLaunchKernelGGL((k_surface_mixed<false, true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    else if (mixed && ctx->simple_shading) hipLaunchKernelGGL((k_surface_mixed<true, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    else if (mixed) hipLaunchKernelGGL((k_surface_mixed<false, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    else if (lds) hipLaunchKernelGGL((k_surface<true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    else hipLaunchKernelGGL((k_surface<false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
     if (mixed) hipLaunchKernelGGL((k_surface_redo<true>), dim3(64), dim3(BLOCK), 0, ctx->stream, D);
     ctx->end();
     for (int level = D.n_levels - 1; level >= 0; --level) {
@@ -918,7 +968,7 @@ int rt_set_output(RtContext* ctx, void* device_rgb) {
 
 int rt_set_precision(RtContext* ctx, int32_t mode) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
-    if (mode != RT_PRECISION_F64 && mode != RT_PRECISION_MIXED) return fail(RT_ERR_INVALID, "unknown precision mode %d", mode);
+    if (mode != RT_PRECISION_F64 && mode != RT_PRECISION_MIXED && mode != RT_PRECISION_MIXED_CHECKED) return fail(RT_ERR_INVALID, "unknown precision mode %d", mode);
     ctx->precision = mode;
     return RT_OK;
 }
@@ -984,7 +1034,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     const int K = ctx->tree.n_nodes(), Lv = ctx->tree.n_levels();
     std::vector<int32_t> n(K), ng(K), h(K), nt(Lv), tb(Lv);
     int32_t flag = 0;
-    unsigned long long work[5] = {0, 0, 0, 0, 0};
+    unsigned long long work[6] = {0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(work, ctx->work.p, sizeof work, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(n.data(), ctx->node_n.p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
     for (int l = 0; l < Lv; ++l) {
@@ -1012,6 +1062,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     out->n_nodes = K;
     out->n_levels = Lv;
     out->overflow = flag;
+    out->certify_mismatches = (int32_t)std::min<unsigned long long>(work[5], 0x7FFFFFFFull);
     return RT_OK;
 }
 

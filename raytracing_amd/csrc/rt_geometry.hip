@@ -44,6 +44,7 @@ __global__ void k_init(Dev D) {
         D.work[2] = 0;
         D.work[3] = 0;
         D.work[4] = 0;
+        D.work[5] = 0;
         if ((uint32_t)nt > D.cap_tiles) {
             D.flags[0] = 1;
             nt = 0;

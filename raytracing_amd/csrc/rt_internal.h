@@ -38,9 +38,20 @@ constexpr uint32_t I_LIVE_TI = 1u << 22;  // the ray's refraction slot reaches t
 constexpr uint32_t I_LIVE_R = 1u << 23;   // ... and so does its reflection slot
 constexpr int I_BEAM_SHIFT = 24;          // bit 24 + l: hit lies inside spotlight l's beam
 
+// Float32 constants of a disk or spot light for the float32 sample loop (k_surface_mixed).
+struct LightF32 {
+    float xh[3], yh[3];   // the disk's frame times its radius
+    float ps;             // intensity / n_points
+    float extent;         // no light point is farther than this from the disk's centre
+    float dcol[3], scol[3];
+    float ps_grey;        // ps times the light's grey level (lights whose colour has three equal channels)
+    float pad;
+};
+
 // Scene constants kept in device memory and read through scalar loads.
 struct SceneConst {
     RtLight lights[RT_MAX_LIGHTS];
+    LightF32 lightf[RT_MAX_LIGHTS];
     double ambient[3];
     double cam[3];
     double scr_pos[3], scr_x[3], scr_y[3];
@@ -99,7 +110,8 @@ struct Dev {
     uint32_t* wave_off;     // [n_levels][NCNT][NW] counter value at a wave's first tile relative to its workgroup
     int32_t* flags;         // [0] overflow, [1] entries queued for float64 re-evaluation
     unsigned long long* work;  // [0] hits shaded, [1] light samples evaluated, [2] samples queued for float64,
-                               // [3] hit records stored, [4] live hits (cleared by k_init)
+                               // [3] hit records stored, [4] live hits, [5] certified float32 shadow decisions
+                               // that differ from float64 (test mode); cleared by k_init
     // ray arena (structure of arrays, one slot per ray)
     double *px, *py, *pz;   // hit point
     double *dx, *dy, *dz;   // ray direction
@@ -125,7 +137,11 @@ struct Dev {
     // disk-light samples, packed per shading-list entry: for light l, sample s of entry e is the
     // pair packed[2 * (pack_base[l] + s * pack_E + e)] = (angle uniform, radius uniform)
     double* packed;
-    float* packed32;            // the same pairs rounded to float (mixed-precision pass), or null
+    // the same samples for the float32 pass, or null: the points of the unit disk the pairs select, as
+    // floats, tile by tile of 64 shading-list entries; light l, tile t, samples 2p and 2p + 1 of entry
+    // 64 t + i are the float4 (x0, x1, y0, y1) at index pack32_base[l] + (t * ceil(N / 2) + p) * 64 + i
+    float* packed32;
+    int64_t pack32_base[RT_MAX_LIGHTS];
     int64_t pack_base[RT_MAX_LIGHTS];
     int64_t pack_E;             // entries of the shading list when the samples were packed
     const int64_t* sample_off;  // [K][RT_MAX_LIGHTS] offset of each (node, light) block in the caller's stream

@@ -71,7 +71,6 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, 
             }
             if (off + 2 * N * h <= a || off >= b) continue;
             double* dst = D.packed + 2 * (D.pack_base[l] + e);
-            float* dst32 = D.packed32 ? D.packed32 + 2 * (D.pack_base[l] + e) : nullptr;
             for (int part = 0; part < 2; ++part) {
                 const int64_t first = off + (int64_t)part * N * h + jj;     // stream position of row 0
                 int64_t s0 = first >= a ? 0 : (a - first + h - 1) / h;
@@ -80,10 +79,41 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, 
                     if (pos >= b) break;
                     const double u = chunk(pos - a);
                     dst[2 * s * E + part] = u;
-                    if (dst32) dst32[2 * s * E + part] = (float)u;
                 }
             }
         }
+    }
+}
+
+// The float32 sample pass does not start from the pair of uniforms but from the point of the unit
+// disk they select: (sqrt(u_radius) cos(2 pi u_angle), sqrt(u_radius) sin(2 pi u_angle)) (reference
+// objects.py:132-135), evaluated once in float64 when the sample stream is complete and rounded to
+// float.  The light point of a sample is then position + radius * (x * x_hat + y * y_hat).
+// Output layout: see Dev::packed32.  One thread per (tile, pair of samples, entry of the tile); slots
+// beyond the shading list or the sample count hold the disk's centre.
+__global__ __launch_bounds__(BLOCK) void k_disk_points(const double* __restrict__ pairs /* the light's first pair */, int64_t E, int N,
+                                                       float4* __restrict__ points /* the light's first float4 */) {
+    const int NP = (N + 1) >> 1;
+    const int64_t n = ((E + TILE - 1) / TILE) * NP * TILE;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const int lane = (int)(i & (TILE - 1));
+        const int64_t tp = i / TILE;
+        const int p = (int)(tp % NP);
+        const int64_t e = (tp / NP) * TILE + lane;
+        float x[2] = {0, 0}, y[2] = {0, 0};
+        if (e < E) {
+            for (int k = 0; k < 2; ++k) {
+                const int s = 2 * p + k;
+                if (s >= N) break;
+                const double2 u = reinterpret_cast<const double2*>(pairs)[s * E + e];
+                double sn, cs;
+                sincospi(2.0 * u.x, &sn, &cs);
+                const double rad = sqrt(u.y);
+                x[k] = (float)(rad * cs);
+                y[k] = (float)(rad * sn);
+            }
+        }
+        points[i] = make_float4(x[0], x[1], y[0], y[1]);
     }
 }
 
