@@ -19,8 +19,8 @@ __device__ __forceinline__ v2f vclip01(v2f a) { return {fclip01(a.x), fclip01(a.
 __device__ __forceinline__ v2f vdot(F3 a, F3x2 b) { return vfma(b.z, a.z, vfma(b.y, a.y, b.x * a.x)); }
 
 constexpr int MIXED_MAX_SPHERES = 64;   // scenes up to this many spheres take the float32 sample pass (one 64-bit
-                                        // mask of candidate spheres per wave)
-constexpr int MIXED_T = 4;              // candidate spheres of a wave that the sample loop keeps in registers
+                                        // mask of candidate spheres per hit)
+constexpr int MIXED_T = 4;              // candidate spheres of a hit that the sample loop keeps in registers
 #ifndef RT_PAIR_BATCH
 #define RT_PAIR_BATCH 3
 #endif
@@ -42,12 +42,15 @@ struct DiskHit {
     float nd2;   // -2 n.d:  r.d = L.d - 2 (n.L)(n.d)
     float sh;    // shininess
     float eLk;   // error of the computed light vector before the division by its length
+    float ps;    // light intensity per sample (SIMPLE: times the light's grey level) times the transparency of
+                 // every sphere the hit lies inside: such a sphere is met by every shadow ray of the hit with
+                 // a zero-length path to its near side, so it multiplies by its transparency alone
+                 // (reference objects.py:274-285 with min_t = max_t)
     F3 kdf, ksf; // diffuse / specular colour times coefficient (read by the general variant only)
 };
 // The light, the same for every lane (scalar registers).
 struct DiskLightConst {
     F3 xh, yh;   // disk frame times the radius
-    float ps;    // intensity / n_points (SIMPLE: times the light's grey level)
     F3 dcol, scol;
 };
 // Sums over the samples of one hit and one light.
@@ -73,6 +76,7 @@ struct SampleSums<false> {
 struct CertifyCheck {
     const Dev* D;
     const ShadowSphere* s_sh;
+    uint64_t within;       // spheres the hit lies inside: met by every sample
     const double* pk64;    // the hit's first pair of uniforms in the float64 sample buffer
     int64_t stride64;      // doubles from one sample to the next
     V3 Pb, lpos, xh, yh;
@@ -161,8 +165,8 @@ __device__ __forceinline__ void eval_pair(const float4 u, const v2f w, const boo
         unsure |= (un0 && on0) || (un1 && on1);
     }
     if constexpr (CHECK) {
-        if (on0) mismatches += certify_mismatches(ck, s_first, ck_hit0, ck_un0);
-        if (on1) mismatches += certify_mismatches(ck, s_first + 1, ck_hit1, ck_un1);
+        if (on0) mismatches += certify_mismatches(ck, s_first, ck_hit0 | ck.within, ck_un0);
+        if (on1) mismatches += certify_mismatches(ck, s_first + 1, ck_hit1 | ck.within, ck_un1);
     }
     // transmittance of the occluders (reference objects.py:274-285) as one exponential per channel:
     // the product over spheres of tr * exp(-k * chord) is exp2(sum of log2(tr) - k * log2(e) * chord),
@@ -195,7 +199,7 @@ __device__ __forceinline__ void eval_pair(const float4 u, const v2f w, const boo
             if (hit1) mult1 = {__builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y), __builtin_amdgcn_exp2f(e1.z)};
         }
     }
-    const v2f fall = inv * inv * L.ps;
+    const v2f fall = inv * inv * H.ps;
     const v2f nl = vdot(H.nf, Lh);
     const v2f rd = vfma(nl, H.nd2, vdot(H.df, Lh));
     // |r.d|^shininess; |r.d| = 0 with shininess 0 gives NaN here, which fminf turns into 1 (0^0 = 1)
@@ -268,14 +272,14 @@ __device__ __forceinline__ void disk_samples(const float4* __restrict__ pk, cons
 // objects.py:94-235).  One wave per tile of 64 list entries; entry e's samples are slot e % 64 of
 // tile e / 64 in the float32 sample buffer.
 //
-// Per hit and sampled light, spheres no sample can touch are ruled out first: all unit light vectors
-// lie within sigma of the direction to the disk's centre (the light points lie within `extent` of the
-// centre, which is dc away; for extent <= dc / 2 the angle is at most asin(extent / dc) <= 1.05 extent
-// / dc, and so is the length of the difference), so b = oc.L stays within |oc| sigma of its value
-// there; a sphere the origin is outside of is missed by every sample if b stays positive (it lies
-// behind every shadow ray) or b^2 stays below C.  The spheres some hit of the wave still needs are the
-// wave's candidates; up to MIXED_T of them are tested per sample (a candidate another lane needs is a
-// certain miss for this lane: C = +inf), a wave with more goes to the float64 re-evaluation.
+// Per hit and sampled light, spheres no sample can touch are ruled out first: every unit light vector
+// makes an angle of at most asin(extent / dc) with the direction to the disk's centre (the light points
+// lie within `extent` of the centre, which is dc away), which bounds b = oc.L from both sides;
+// a sphere the origin is outside of is missed by every sample if b stays positive (it lies
+// behind every shadow ray) or b^2 stays below C.  The spheres a hit still needs are its candidates: up
+// to MIXED_T of them, each lane its own, are tested per sample (the sample loop has as many slots as
+// the hit of the wave with the most candidates needs; a hit with fewer leaves slots empty: C = +inf);
+// a hit with more goes to the float64 re-evaluation.
 template <bool SIMPLE, bool CHECK>
 __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) {
     __shared__ ShadowSphere s_sh[MIXED_MAX_SPHERES];
@@ -314,28 +318,41 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
         V3 surf = {0, 0, 0};
         bool redo = false;
         unsigned hit_samples = 0;   // light samples of this hit
+        // point lights first, in float64 (the float32 pass is held to a looser tolerance anyway, so the order
+        // in which the lights' contributions are added need not be the reference's): after this loop the
+        // float64 normal and direction are no longer needed
         for (int l = 0; l < D.n_lights; ++l) {
-            const int kind = sc->lights[l].kind;
+            if (sc->lights[l].kind != RT_LIGHT_POINT) continue;
             const V3 lpos = {sc->lights[l].position[0], sc->lights[l].position[1], sc->lights[l].position[2]};
             const V3 kdiff = ld3(s_mat[sid].kdiff), kspec = ld3(s_mat[sid].kspec);
             const double shin = s_mat[sid].shininess;
-            if (kind == RT_LIGHT_POINT) {
-                const V3 dcol = {sc->lights[l].diffuse_color[0], sc->lights[l].diffuse_color[1], sc->lights[l].diffuse_color[2]};
-                const V3 scol = {sc->lights[l].specular_color[0], sc->lights[l].specular_color[1], sc->lights[l].specular_color[2]};
-                const V3 Lv = lpos - Pb;
-                const double dist = sqrt(dot(Lv, Lv));
-                const V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
-                const V3 mult = shadow_multiplier<true>(D, s_sh, no_lists, Pb, Lh);
-                const double fall = sc->lights[l].intensity / (dist * dist);
-                const V3 Id = clip01((fall * dcol) * mult), Is = clip01((fall * scol) * mult);
-                const double nl = dot(n, Lh);
-                const V3 Rv = Lh - (2 * nl) * n;
-                const double rd = fabs(dot(Rv, d));
-                const V3 kd = clip01(nl * kdiff), ks = clip01(pow_shininess(rd, shin) * kspec);
-                surf = surf + clip01(clip01(kd * Id) + clip01(ks * Is));
-                if (active) hit_samples += 1;
-                continue;
-            }
+            const V3 dcol = {sc->lights[l].diffuse_color[0], sc->lights[l].diffuse_color[1], sc->lights[l].diffuse_color[2]};
+            const V3 scol = {sc->lights[l].specular_color[0], sc->lights[l].specular_color[1], sc->lights[l].specular_color[2]};
+            const V3 Lv = lpos - Pb;
+            const double dist = sqrt(dot(Lv, Lv));
+            const V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
+            const V3 mult = shadow_multiplier<true>(D, s_sh, no_lists, Pb, Lh);
+            const double fall = sc->lights[l].intensity / (dist * dist);
+            const V3 Id = clip01((fall * dcol) * mult), Is = clip01((fall * scol) * mult);
+            const double nl = dot(n, Lh);
+            const V3 Rv = Lh - (2 * nl) * n;
+            const double rd = fabs(dot(Rv, d));
+            const V3 kd = clip01(nl * kdiff), ks = clip01(pow_shininess(rd, shin) * kspec);
+            surf = surf + clip01(clip01(kd * Id) + clip01(ks * Is));
+            if (active) hit_samples += 1;
+        }
+        // what the sample loop needs of the hit, whatever the light
+        DiskHit H;
+        H.nf = f3(n); H.df = f3(d);
+        H.nd2 = -2.0f * fdot(H.nf, H.df);
+        H.sh = (float)s_mat[sid].shininess;
+        if constexpr (!SIMPLE) {
+            H.kdf = f3(ld3(s_mat[sid].kdiff)); H.ksf = f3(ld3(s_mat[sid].kspec));
+        }
+        for (int l = 0; l < D.n_lights; ++l) {
+            const int kind = sc->lights[l].kind;
+            if (kind == RT_LIGHT_POINT) continue;
+            const V3 lpos = {sc->lights[l].position[0], sc->lights[l].position[1], sc->lights[l].position[2]};
             // disk light, possibly restricted to a beam (then hits outside the beam get no light from it)
             bool lit = active;
             double factor = 1.0;
@@ -357,61 +374,73 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
             DiskLightConst L;
             L.xh = {sc->lightf[l].xh[0], sc->lightf[l].xh[1], sc->lightf[l].xh[2]};
             L.yh = {sc->lightf[l].yh[0], sc->lightf[l].yh[1], sc->lightf[l].yh[2]};
-            L.ps = SIMPLE ? sc->lightf[l].ps_grey : sc->lightf[l].ps;
             L.dcol = {sc->lightf[l].dcol[0], sc->lightf[l].dcol[1], sc->lightf[l].dcol[2]};
             L.scol = {sc->lightf[l].scol[0], sc->lightf[l].scol[1], sc->lightf[l].scol[2]};
             const float extent = sc->lightf[l].extent;
             // what the sample loop needs of the hit
             const V3 qd = lpos - Pb;
-            DiskHit H;
-            H.q = f3(qd); H.nf = f3(n); H.df = f3(d);
-            H.nd2 = -2.0f * fdot(H.nf, H.df);
-            H.sh = (float)shin;
-            H.kdf = f3(kdiff); H.ksf = f3(kspec);
+            H.q = f3(qd);
             const float q2 = fdot(H.q, H.q);
             const float inv_dc = __builtin_amdgcn_rsqf(q2);
             H.eLk = 2.5e-7f * (extent + q2 * inv_dc);
             const F3 chat = {H.q.x * inv_dc, H.q.y * inv_dc, H.q.z * inv_dc};
-            const float spread = extent * inv_dc;
-            const bool narrow = spread <= 0.5f;
-            const float sigma = 1.1f * spread + 4e-6f;   // 4e-6: float rounding of chat, oc and the dot product below
-            // candidates: spheres some sample of some hit of the wave may touch
-            uint64_t cand = 0, need = 0;
+            // sine of the largest angle between a unit light vector and chat (the disk lies in a ball of
+            // radius extent around its centre, which is 1 / inv_dc away), with room for float rounding
+            const float spread = extent * inv_dc * 1.000002f + 1e-7f;
+            const bool narrow = spread <= 0.9f;
+            // candidates: the spheres some sample of this hit may touch
+            uint64_t need = 0, within = 0;
+            float tr_within = 1.0f;
             for (int i = 0; i < S; ++i) {
                 const V3 oc = {Pb.x - s_sh[i].cx, Pb.y - s_sh[i].cy, Pb.z - s_sh[i].cz};
                 const double l2 = dot(oc, oc), r2 = s_sh[i].r2, C = l2 - r2;
                 const float len = __builtin_amdgcn_sqrtf((float)l2) * 1.000001f;
                 const double c1 = fabs(s_sh[i].cx) + fabs(s_sh[i].cy) + fabs(s_sh[i].cz);
                 const double noise = 2e-15 * (l2 + r2) + 4e-15 * (pb1 + c1) * (double)len;   // float64 rounding of C
+                // b = oc.L for a unit vector L at most that angle from chat: with bc = oc.chat and perp the
+                // part of oc across chat, |b - bc cos| <= perp sin; the sphere lies behind every shadow ray
+                // if the smallest b is positive, and no ray reaches it if the largest b^2 stays below C
                 const float bc = fdot(f3(oc), chat);
-                const float reach = len * sigma;
-                const float bm = fabsf(bc) + reach;
-                const bool ruled_out = narrow && C > noise && (bc > reach || bm * bm < (float)C * 0.999998f);
-                const bool keep = lit && !ruled_out;
-                if (__ballot(keep) != 0) cand |= 1ull << i;
-                if (keep) need |= 1ull << i;
+                const float l2f = len * len;
+                const float perp = __builtin_amdgcn_sqrtf(fmaxf(l2f - bc * bc, 0.0f) + 4e-6f * l2f) * spread;
+                const float slack = 4e-6f * len;   // float rounding of chat, oc and bc
+                const float bm = fabsf(bc) + perp + slack;
+                const bool ruled_out = narrow && C > noise && (bc * (1.0f - spread * spread) - perp > slack || bm * bm < (float)C * 0.999998f);
+                const bool inside = C < -noise;   // every sample meets this sphere: see DiskHit::ps
+                if (inside) tr_within *= (float)s_sh[i].tr;
+                if (CHECK && inside) within |= 1ull << i;
+                if (lit && !ruled_out && !inside) need |= 1ull << i;
             }
+            H.ps = (SIMPLE ? sc->lightf[l].ps_grey : sc->lightf[l].ps) * tr_within;
 #ifdef RT_DBG_FORCE_T0
-            cand = 0;
+            need = 0;
 #endif
-            const int Tn = __popcll(cand);
-#ifdef RT_MIXED_STATS
-            if (lane == 0) { my_mismatches += 1u << (8 * min(Tn, 3)); }   // histogram: bytes 0..3 = waves with T = 0, 1, 2, >= 3 (overflows: debug only)
-#endif
-            if (Tn > MIXED_T) {
-                redo = redo || lit;
-                continue;
+            int mine = __popcll(need);
+            const bool too_many = mine > MIXED_T;
+            if (too_many) {   // more candidates than the sample loop holds: this hit goes to the float64 re-evaluation
+                redo = true;
+                need = 0;
+                mine = 0;
             }
+            // slots of the sample loop: the largest number of candidates of any hit of the wave
+            int Tn = 0;
+#pragma unroll
+            for (int k = 1; k <= MIXED_T; ++k)
+                if (__ballot(mine >= k) != 0) Tn = k;
+#ifdef RT_MIXED_STATS
+            if (lane == 0 && Tn == RT_MIXED_STATS) my_mismatches += 1;   // debug build: waves with this many slots
+#endif
             HitSphere hs[MIXED_T];
             int idx[MIXED_T];
             {
-                uint64_t rest = cand;
+                uint64_t rest = need;
 #pragma unroll
                 for (int j = 0; j < MIXED_T; ++j) {
                     idx[j] = 0;
                     hs[j] = {{0, 0, 0}, __builtin_inff(), 0, 0};
-                    if (j < Tn) {
-                        const int i = __builtin_ctzll(rest);
+                    if (j < Tn) {   // the same in every lane; a hit with fewer candidates leaves the slot empty (C = +inf)
+                        const bool used = rest != 0;
+                        const int i = used ? __builtin_ctzll(rest) : 0;
                         rest &= rest - 1;
                         idx[j] = i;
                         const V3 oc = {Pb.x - s_sh[i].cx, Pb.y - s_sh[i].cy, Pb.z - s_sh[i].cz};
@@ -422,7 +451,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
                         hs[j].oc = f3(oc);
                         hs[j].len2 = 2.0f * (len + 1e-9f * (float)(pb1 + c1));
                         hs[j].k0 = fabs(C) <= noise ? __builtin_inff() : (float)(1.5e-7 * fabs(C) + noise);
-                        hs[j].C = ((need >> i) & 1u) ? (float)C : __builtin_inff();
+                        hs[j].C = used ? (float)C : __builtin_inff();
                     }
                 }
             }
@@ -430,7 +459,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
             const float4* pk = reinterpret_cast<const float4*>(D.packed32) + D.pack32_base[l] + ((int64_t)tile * NP * TILE + lane);
             CertifyCheck ck{};
             if constexpr (CHECK) {
-                ck.D = &D; ck.s_sh = s_sh;
+                ck.D = &D; ck.s_sh = s_sh; ck.within = within;
                 ck.pk64 = D.packed + 2 * (D.pack_base[l] + (active ? e : total - 1));
                 ck.stride64 = 2 * D.pack_E;
                 ck.Pb = Pb; ck.lpos = lpos;
@@ -454,7 +483,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
 #endif
             if (lit) {
                 redo = redo || unsure;
-                if (CHECK && !unsure) my_mismatches += mismatches;
+                if (CHECK && !unsure && !too_many) my_mismatches += mismatches;
             }
             V3 sumId, sumIs, sumKd, sumKs;
             if constexpr (SIMPLE) {
@@ -463,8 +492,8 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
                          (double)(open + (A.shaded.z.x + A.shaded.z.y))};
                 sumIs = sumId;
                 const double sN = (double)(A.nl.x + A.nl.y), sP = (double)(A.pw.x + A.pw.y);
-                sumKd = sN * kdiff;
-                sumKs = sP * kspec;
+                sumKd = sN * ld3(s_mat[sid].kdiff);
+                sumKs = sP * ld3(s_mat[sid].kspec);
             } else {
                 auto both = [](const F3x2& v) -> V3 { return {(double)(v.x.x + v.x.y), (double)(v.y.x + v.y.y), (double)(v.z.x + v.z.y)}; };
                 sumId = both(A.Id); sumIs = both(A.Is); sumKd = both(A.Kd); sumKs = both(A.Ks);
@@ -485,7 +514,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
             my_samples += hit_samples;
             D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
             if (redo) {
-                // some shadow decision of this hit could not be certified in float32 (or the wave had more
+                // some shadow decision of this hit could not be certified in float32 (or the hit had more
                 // candidate spheres than the sample loop holds): k_surface_redo evaluates the hit again
                 my_fallback += hit_samples;
                 D.redo_list[atomicAdd(&D.flags[1], 1)] = (uint32_t)e;

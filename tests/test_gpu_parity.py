@@ -664,3 +664,71 @@ def test_hierarchy_matches_plain_screening_at_full_size():
     assert out["1"][1:] == out["0"][1:]
     assert out["1"][1] == 482_185_288 and out["1"][2] == 376_397_367      # as measured when the scene was first rendered
     assert np.array_equal(out["1"][0], out["0"][0])
+
+
+# ---------------------------------------------------------------------------------------------
+# The float32 sample pass claims that every shadow decision it does not hand to the float64
+# re-evaluation equals the float64 decision.  "mixed_checked" re-evaluates every certified
+# (sample, sphere) decision in float64 on the device and counts the differences.
+
+def _disk_scene(width, height, offset=(0.0, 0.0, 0.0), light_radius=3.0, light_z=10.0, light_x=4.0, n_points=30,
+                extra_spheres=0, spot=False):
+    """example_4's content (reference Scenes/example_4.py:6-22), optionally moved away from the origin,
+    with another light geometry, or with more small spheres (glass and opaque, some overlapping)."""
+    from raytracing_amd import materials, objects
+    from raytracing_amd.constants import BLUE, GREEN, GREY, RED, WHITE, YELLOW
+    from raytracing_amd.Scenes.Scene import Scene
+    ox, oy, oz = offset
+    M = materials.Material
+    spheres = [objects.Sphere(x=4 + ox, y=oy, z=-10000000 + oz, radius=10000000,
+                              material=M(diffuse_color=WHITE, reflection_coefficient=0, smoothness=1)),
+               objects.Sphere(x=ox, y=oy, z=1 + oz, radius=1,
+                              material=M(diffuse_color=GREEN, reflection_coefficient=0, specular_coefficient=1,
+                                         transparency_coefficient=0.9, refractive_index=1.05, smoothness=1,
+                                         attenuation_coefficient=0.5)),
+               objects.Sphere(x=15 + ox, y=oy, z=2 + oz, radius=4, material=M(diffuse_color=RED, smoothness=0.6))]
+    rs = np.random.RandomState(11)
+    palette = [BLUE, YELLOW, GREY, RED, GREEN]
+    for i in range(extra_spheres):
+        x, y, r = rs.uniform(1.5, 9), rs.uniform(-3, 3), rs.uniform(0.25, 0.7)
+        glass = i % 2 == 0
+        mat = (M(diffuse_color=palette[i % 5], transparency_coefficient=0.8, refractive_index=1.3, smoothness=0.5,
+                 attenuation_coefficient=0.4) if glass else M(diffuse_color=palette[i % 5], reflection_coefficient=0.2))
+        spheres.append(objects.Sphere(x=x + ox, y=y + oy, z=rs.uniform(0.8, 1.2) * r + oz, radius=r, material=mat))
+    if spot:
+        light = objects.DirectionalDiskSource(x=light_x + ox, y=oy, z=light_z + oz, radius=light_radius, intensity=100, angle=25,
+                                              easing_mode="cubic")
+        light.n_points = n_points
+    else:
+        light = objects.DiskSource(x=light_x + ox, y=oy, z=light_z + oz, radius=light_radius, intensity=100, N=n_points)
+    camera = objects.Camera(x=-4 + ox, y=1 + oy, z=1 + oz, viewing_direction=np.array([1.0, 0.0, -0.1]),
+                            pixels_x=width, pixels_y=height)
+    return Scene(spheres, [light], camera, camera.screen, objects.AmbientLight(intensity=1 / 10, color=WHITE))
+
+
+CERTIFY_SCENES = {
+    "example_4_500": lambda: build_scene("example_4", 500, 500),
+    "spot_linear": lambda: synthetic.spotlight_scene("linear", 64, 128, 72),
+    "spot_exponential": lambda: synthetic.spotlight_scene("exponential", 64, 128, 72),
+    "far_from_origin": lambda: _disk_scene(200, 113, offset=(1.0e5, -2.0e5, 3.0e4)),
+    "tiny_light": lambda: _disk_scene(200, 113, light_radius=0.01),            # hard shadows: rays graze the occluders
+    "odd_sample_count": lambda: _disk_scene(160, 90, n_points=7),
+    "light_near_the_ground": lambda: _disk_scene(200, 113, light_radius=2.0, light_z=1.5, light_x=6.0),  # grazing, wide cone
+    "light_touching_hits": lambda: _disk_scene(160, 90, light_radius=6.0, light_z=2.5),   # extent above half the distance
+    "nine_spheres": lambda: _disk_scene(200, 113, extra_spheres=6),
+    "forty_spheres_spot": lambda: _disk_scene(200, 113, extra_spheres=37, spot=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CERTIFY_SCENES))
+def test_certified_float32_shadow_decisions_equal_float64(name):
+    scene = CERTIFY_SCENES[name]()
+    want, _, _, _, _, cnt64 = _render(scene, seed=5, precision="f64")
+    got, _, _, _, _, cnt = _render(scene, seed=5, precision="mixed_checked")
+    assert cnt["certify_mismatches"] == 0
+    assert np.abs(got - want).max() <= TOL_MIXED
+    assert cnt["shaded_samples"] == cnt64["shaded_samples"] > 0
+    # the float32 pass must do the bulk of the work itself
+    assert cnt["fallback_samples"] <= 0.05 * cnt["shaded_samples"], (cnt["fallback_samples"], cnt["shaded_samples"])
+    plain = _render(scene, seed=5, precision="mixed")
+    assert np.array_equal(plain[0], got)
