@@ -19,6 +19,7 @@
 #ifndef RAYTRACING_AMD_H
 #define RAYTRACING_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -292,8 +293,14 @@ int rt_shade(RtContext *ctx);
  * context's own buffer.  NULL switches back.  Call after rt_begin_frame. */
 int rt_set_output(RtContext *ctx, void *device_rgb);
 
-/* Copy the frame's colours, [n_pixels][3] float64 in pixel order (synchronises). */
+/* Copy the frame's colours, [n_pixels][3] float64 in pixel order (synchronises): the array that
+ * reference raytrace.py:278 returns.  Into memory from rt_alloc_host the copy is one transfer at the
+ * host link's rate; other host memory is filled through page-locked pieces of the context. */
 int rt_read_image(RtContext *ctx, double *out_rgb);
+/* Page-locked host memory for images (a current GPU is needed; no counterpart in the reference,
+ * whose arrays are ordinary NumPy memory).  Free with rt_free_host. */
+int rt_alloc_host(size_t bytes, void **out);
+void rt_free_host(void *p);
 /* The reference's output step (reference main.py:32, matplotlib imsave of the float
  * image): 8-bit channels, value = (uint8)(v * 255) of the clipped colour, [n_pixels][3].
  * rt_quantise_rgb8 converts the shaded frame on the device into caller-owned DEVICE

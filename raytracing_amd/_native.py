@@ -100,6 +100,8 @@ SIGNATURES = {
     "rt_set_sample_layout_global": (C.c_int, [_P, _I64P, _I64P, _I64P, C.c_int64]),
     "rt_generate_samples": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "rt_set_precision": (C.c_int, [_P, C.c_int32]),
+    "rt_alloc_host": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "rt_free_host": (None, [_P]),
     "rt_shade": (C.c_int, [_P]),
     "rt_set_output": (C.c_int, [_P, _P]),
     "rt_read_image": (C.c_int, [_P, _F64P]),
@@ -379,8 +381,19 @@ class Context:
         """Write the frame into caller-owned device memory (None: the context's own buffer)."""
         _check(self.lib.rt_set_output(self._h, _P(device_ptr) if device_ptr else None))
 
+    def _host_array(self, shape, dtype):
+        """NumPy array in page-locked memory of the library (freed when the array is collected):
+        the device-to-host copy into it runs at the link's rate."""
+        import weakref
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = _P()
+        _check(self.lib.rt_alloc_host(n, C.byref(p)))
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        weakref.finalize(buf, self.lib.rt_free_host, _P(p.value))
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
     def read_image(self):
-        out = np.empty((self.npix, 3), dtype=np.float64)
+        out = self._host_array((self.npix, 3), np.float64)
         _check(self.lib.rt_read_image(self._h, _ptr(out, C.c_double)))
         return out
 
@@ -389,7 +402,7 @@ class Context:
         _check(self.lib.rt_quantise_rgb8(self._h, _P(device_ptr) if device_ptr else None))
 
     def read_image_rgb8(self):
-        out = np.empty((self.npix, 3), dtype=np.uint8)
+        out = self._host_array((self.npix, 3), np.uint8)
         _check(self.lib.rt_read_image_rgb8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 

@@ -158,12 +158,15 @@ struct RtContext {
     bool simple_shading = false;   // see SampleSums in rt_lighting_mixed.hip: coefficients in [0, 1], grey lights
     int64_t pack_base[RT_MAX_LIGHTS] = {0};
     int64_t pack_E = 0;
+    int64_t pack_plane = 0;   // doubles from a sample's angle uniform to its radius uniform in `packed`
     DevBuf<int64_t> sample_off, sample_global;
     bool have_global_layout = false;
     int64_t global_total = 0;
     DevBuf<unsigned long long> work;
     double* user_image = nullptr;
     DevBuf<uint8_t> image8;
+    char* bounce = nullptr;          // page-locked staging for reads into pageable host memory (2 x BOUNCE_BYTES)
+    hipEvent_t bounce_done[2] = {nullptr, nullptr};
     DevBuf<uint32_t> mt_ring, mt_raw, mt_polys;
     DevBuf<long long> mt_end;
     uint8_t* user_image8 = nullptr;
@@ -209,7 +212,7 @@ struct RtContext {
         D.spot_mask = spot_mask;
         D.X = explicit_xy ? X.p : nullptr; D.Y = explicit_xy ? Y.p : nullptr;
         D.row0 = row0; D.npix = (int32_t)npix;
-        D.packed = packed.p; D.packed32 = have_packed32 ? packed32.p : nullptr; D.pack_E = pack_E; D.sample_off = sample_off.p; D.sample_global = have_global_layout ? sample_global.p : nullptr;
+        D.packed = packed.p; D.pack_plane = pack_plane; D.packed32 = have_packed32 ? packed32.p : nullptr; D.pack_E = pack_E; D.sample_off = sample_off.p; D.sample_global = have_global_layout ? sample_global.p : nullptr;
         for (int l = 0; l < RT_MAX_LIGHTS; ++l) { D.pack_base[l] = pack_base[l]; D.pack32_base[l] = pack32_base[l]; }
         D.image = user_image ? user_image : image.p;
         return D;
@@ -284,6 +287,41 @@ int launch_level(RtContext* ctx, int level) {
     hipLaunchKernelGGL(k_link, dim3(NB), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
     ctx->end();
     HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// Device-to-host copy of a frame.  Into page-locked memory (rt_alloc_host) it is one transfer at the
+// link's rate; into pageable memory the runtime's own staging is several times slower, so the
+// data goes through two page-locked pieces of the context instead, one travelling while the other
+// is copied out.  Waits for the stream.
+constexpr size_t BOUNCE_BYTES = 8u << 20;
+int copy_to_host(RtContext* ctx, void* dst, const void* src_device, size_t bytes) {
+    hipPointerAttribute_t attr{};
+    const bool pinned = hipPointerGetAttributes(&attr, dst) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();   // pageable memory is reported as an error; it is none
+    if (pinned || bytes <= BOUNCE_BYTES) {
+        HIP_TRY(hipMemcpyAsync(dst, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    }
+    if (!ctx->bounce) {
+        HIP_TRY(hipHostMalloc((void**)&ctx->bounce, 2 * BOUNCE_BYTES, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->bounce_done[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->bounce_done[1], hipEventDisableTiming));
+    }
+    const size_t pieces = (bytes + BOUNCE_BYTES - 1) / BOUNCE_BYTES;
+    for (size_t i = 0; i <= pieces; ++i) {
+        if (i < pieces) {
+            const size_t off = i * BOUNCE_BYTES, len = std::min(BOUNCE_BYTES, bytes - off);
+            HIP_TRY(hipMemcpyAsync(ctx->bounce + (i & 1) * BOUNCE_BYTES, (const char*)src_device + off, len, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipEventRecord(ctx->bounce_done[i & 1], ctx->stream));
+        }
+        if (i > 0) {
+            const size_t j = i - 1, off = j * BOUNCE_BYTES, len = std::min(BOUNCE_BYTES, bytes - off);
+            HIP_TRY(hipEventSynchronize(ctx->bounce_done[j & 1]));
+            memcpy((char*)dst + off, ctx->bounce + (j & 1) * BOUNCE_BYTES, len);
+        }
+    }
     return RT_OK;
 }
 
@@ -380,6 +418,8 @@ void rt_destroy(RtContext* ctx) {
     for (auto& b : ctx->list_j) b.release();
     ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->packed32.release(); ctx->staging.release();
     ctx->image.release(); ctx->image8.release(); ctx->mt_ring.release(); ctx->mt_raw.release(); ctx->mt_polys.release(); ctx->mt_end.release(); ctx->sample_off.release(); ctx->sample_global.release(); ctx->work.release();
+    if (ctx->bounce) (void)hipHostFree(ctx->bounce);
+    for (auto e : ctx->bounce_done) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -711,6 +751,7 @@ int rt_set_sample_layout(RtContext* ctx, const int64_t* offsets, int64_t total) 
         if (ctx->sc_host.lights[l].kind != RT_LIGHT_POINT) slots += (int64_t)ctx->sc_host.lights[l].n_points * entries;
     }
     HIP_TRY(ctx->packed.ensure((size_t)slots * 2));
+    ctx->pack_plane = slots;
     // scenes the float32 sample pass can take also keep the samples' disk points as floats (Dev::packed32)
     ctx->have_packed32 = ctx->S <= MIXED_MAX_SPHERES;
     if (ctx->have_packed32) {
@@ -819,13 +860,17 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     while (((next + (1ll << ell) - 1) >> ell) > 1024) ++ell;
     const long long L = 1ll << ell;
     const int T = (int)((next + L - 1) >> ell);
-    // words held in memory at a time (whole streams); RT_MT_RAW_WORDS overrides for tests
-    long long budget = 1ll << 32;
+    // words held in memory at a time (whole streams): all of them if a good part of the free device
+    // memory holds them (then every stream is generated in one launch, four workgroups to a
+    // compute unit); RT_MT_RAW_WORDS overrides for tests
+    size_t free_bytes = 0, total_bytes = 0;
+    HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
+    long long budget = std::max<long long>(1ll << 28, (long long)(free_bytes / 2 / sizeof(uint32_t)));
     if (const char* e = getenv("RT_MT_RAW_WORDS")) budget = std::max(1ll, atoll(e));
     const int per_pass = (int)std::max<long long>(1, std::min<long long>(T, budget >> ell));
 
-    HIP_TRY(ctx->mt_ring.ensure((size_t)(T + 1) * MT_RING));
-    HIP_TRY(ctx->mt_end.ensure((size_t)T + 1));
+    HIP_TRY(ctx->mt_ring.ensure((size_t)T * MT_RING));
+    HIP_TRY(ctx->mt_end.ensure((size_t)T));
     HIP_TRY(ctx->mt_raw.ensure((size_t)per_pass * L + 2));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::vector<uint32_t> ring(MT_RING, 0u);
@@ -835,22 +880,16 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     HIP_TRY(hipMemcpy(ctx->mt_end.p, &first_end, sizeof first_end, hipMemcpyHostToDevice));
 
     if (T > 1) {
-        // start windows of streams 1 .. T-1 by jump-ahead from the window at L - 1, which a
-        // scratch copy of stream 0 (ring T) reaches sequentially
-        int n_polys = 1;                                   // bits of T - 2, the largest t - 1
-        while (((T - 2) >> n_polys) > 0) ++n_polys;
+        // start windows of streams 1 .. T-1 by jump-ahead from the key block
+        int n_polys = 1;                                   // bits of T - 1, the largest t
+        while (((T - 1) >> n_polys) > 0) ++n_polys;
         std::vector<uint32_t> polys((size_t)n_polys * MT_N);
         for (int b = 0; b < n_polys; ++b)
             if (!mtjump::pow2_words(ell + b, polys.data() + (size_t)b * MT_N))
                 return fail(RT_ERR_INVALID, "MT19937 jump tables unavailable (stream too long?)");
         HIP_TRY(ctx->mt_polys.ensure(polys.size()));
         HIP_TRY(hipMemcpy(ctx->mt_polys.p, polys.data(), polys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ctx->mt_ring.p + (size_t)T * MT_RING, ring.data(), MT_RING * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ctx->mt_end.p + T, &first_end, sizeof first_end, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, (uint32_t*)nullptr,
-                           T, ell, 0ll, 0ll, T, L - 1 + MT_N);
-        hipLaunchKernelGGL(k_mt_jump, dim3(T - 1), dim3(640), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, T, 0ll,
-                           ctx->mt_polys.p, n_polys, ell);
+        hipLaunchKernelGGL(k_mt_jump, dim3(T - 1), dim3(640), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, ctx->mt_polys.p, n_polys, ell);
     }
     // The state NumPy would be left in: the key block that holds the last word consumed and
     // the position after it (a position of 624 means "regenerate at the next draw").
@@ -860,12 +899,14 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     const int64_t pack_blocks = std::max<int64_t>(1, std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB));
     for (int t0 = 0; t0 < T; t0 += per_pass) {
         const int n_streams = std::min(per_pass, T - t0);
-        const long long w_lo = (long long)t0 << ell;                                   // first word of the pass
-        const long long w_hi = std::min(((long long)(t0 + n_streams) << ell) + 1, next); // one past its last word
+        const long long w_lo = (long long)t0 << ell;                                   // origin of the pass's buffer
+        const long long w_first = w_lo + (t0 > 0 ? 1 : 0);                             // first word the pass delivers
+        const long long w_hi = std::min(((long long)(t0 + n_streams) << ell) + 2, next); // one past its last word
         hipLaunchKernelGGL(k_mt_generate, dim3(n_streams), dim3(256), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, ctx->mt_raw.p,
                            t0, ell, w_lo, w_hi, last_stream, (block + 1) * MT_N);
-        // values whose two words both lie in [w_lo, w_hi): value p uses words pos + 2p, pos + 2p + 1
-        const long long p_lo = w_lo <= pos ? 0 : (w_lo - pos + 1) / 2;
+        // values whose two words both lie in [w_first, w_hi): value p uses words pos + 2p, pos + 2p + 1
+        // (a value that straddles two passes is whole in the earlier one: it reaches two words further)
+        const long long p_lo = w_first <= pos ? 0 : (w_first - pos + 1) / 2;
         const long long p_hi = (w_hi - 2 - pos) / 2;                                   // inclusive
         if (ctx->pack_E > 0 && p_hi >= p_lo && w_hi - 2 - pos >= 0)
             hipLaunchKernelGGL((k_pack<GeneratedStream>), dim3((unsigned)pack_blocks), dim3(BLOCK), 0, ctx->stream, D,
@@ -883,9 +924,10 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     const long long last_first = (long long)last_stream << ell;
     for (int i = 0; i < MT_N; ++i) {
         const long long n = block * MT_N + i;
-        key_out[i] = (n >= last_first ? ring : prev_ring)[n & (MT_RING - 1)];
+        key_out[i] = (n > last_first ? ring : prev_ring)[n & (MT_RING - 1)];   // the last stream's own first word is not whole
     }
     *pos_out = (int32_t)(next - block * MT_N);
+    ctx->mt_raw.release();   // as large as the whole stream; only needed while it is being packed
     return RT_OK;
 }
 
@@ -914,8 +956,8 @@ int rt_shade(RtContext* ctx) {
             if (L.kind == RT_LIGHT_POINT) continue;
             const int64_t n = ((ctx->pack_E + TILE - 1) / TILE) * ((L.n_points + 1) / 2) * TILE;
             const int64_t blocks = std::min<int64_t>((n + BLOCK - 1) / BLOCK, 16 * NB);
-            hipLaunchKernelGGL(k_disk_points, dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->packed.p + 2 * ctx->pack_base[l],
-                               ctx->pack_E, L.n_points, reinterpret_cast<float4*>(ctx->packed32.p) + ctx->pack32_base[l]);
+            hipLaunchKernelGGL(k_disk_points, dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->packed.p + ctx->pack_base[l],
+                               ctx->pack_plane, ctx->pack_E, L.n_points, reinterpret_cast<float4*>(ctx->packed32.p) + ctx->pack32_base[l]);
         }
         ctx->disk_points_ready = true;
     }
@@ -984,12 +1026,21 @@ int rt_read_image(RtContext* ctx, double* out_rgb) {
     if (!ctx->shaded) return fail(RT_ERR_STATE, "rt_shade has not been called for this frame");
     if (!out_rgb) return fail(RT_ERR_INVALID, "out_rgb is null");
     int32_t flag = 0;
-    HIP_TRY(hipMemcpyAsync(out_rgb, ctx->user_image ? ctx->user_image : ctx->image.p, (size_t)ctx->npix * 3 * sizeof(double),
-                           hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int rc = copy_to_host(ctx, out_rgb, ctx->user_image ? ctx->user_image : ctx->image.p, (size_t)ctx->npix * 3 * sizeof(double))) return rc;
     if (flag) return fail(RT_ERR_OVERFLOW, "ray arena of %lld rays is too small for this frame", (long long)ctx->arena_rays);
     return RT_OK;
+}
+
+int rt_alloc_host(size_t bytes, void** out) {
+    if (!out) return fail(RT_ERR_INVALID, "out is null");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
+    return RT_OK;
+}
+
+void rt_free_host(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int rt_quantise_rgb8(RtContext* ctx, void* device_rgb8) {
@@ -1013,9 +1064,8 @@ int rt_read_image_rgb8(RtContext* ctx, uint8_t* out_rgb8) {
     if (!out_rgb8) return fail(RT_ERR_INVALID, "out_rgb8 is null");
     if (int rc = rt_quantise_rgb8(ctx, nullptr)) return rc;
     int32_t flag = 0;
-    HIP_TRY(hipMemcpyAsync(out_rgb8, ctx->user_image8, (size_t)ctx->npix * 3, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int rc = copy_to_host(ctx, out_rgb8, ctx->user_image8, (size_t)ctx->npix * 3)) return rc;
     if (flag) return fail(RT_ERR_OVERFLOW, "ray arena of %lld rays is too small for this frame", (long long)ctx->arena_rays);
     return RT_OK;
 }

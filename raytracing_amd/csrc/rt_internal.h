@@ -134,9 +134,11 @@ struct Dev {
     const double* Y;        // NULL: whole rows starting at row0
     int32_t row0;
     int32_t npix;
-    // disk-light samples, packed per shading-list entry: for light l, sample s of entry e is the
-    // pair packed[2 * (pack_base[l] + s * pack_E + e)] = (angle uniform, radius uniform)
+    // disk-light samples, packed per shading-list entry: for light l, sample s of entry e has its angle
+    // uniform at packed[pack_base[l] + s * pack_E + e] and its radius uniform pack_plane doubles further on
+    // (two planes, so that both the scatter that fills them and the readers touch whole cache lines)
     double* packed;
+    int64_t pack_plane;
     // the same samples for the float32 pass, or null: the points of the unit disk the pairs select, as
     // floats, tile by tile of 64 shading-list entries; light l, tile t, samples 2p and 2p + 1 of entry
     // 64 t + i are the float4 (x0, x1, y0, y1) at index pack32_base[l] + (t * ceil(N / 2) + p) * 64 + i

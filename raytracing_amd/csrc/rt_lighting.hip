@@ -234,11 +234,11 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
         }
         const int N = Lt.n_points;
         n_samples += N;
-        const double* pk = D.packed + 2 * (D.pack_base[l] + entry);   // + 2 * pack_E per sample
-        const int64_t stride = 2 * D.pack_E;
+        const double* pk = D.packed + D.pack_base[l] + entry;   // + pack_E per sample
+        const int64_t stride = D.pack_E;
         V3 sumId = {0, 0, 0}, sumIs = {0, 0, 0}, sumKd = {0, 0, 0}, sumKs = {0, 0, 0};
         for (int s = 0; s < N; ++s) {
-            const SampleTerms o = disk_sample_f64<LDS>(D, s_sh, cand, Lt, pk[s * stride], pk[s * stride + 1],
+            const SampleTerms o = disk_sample_f64<LDS>(D, s_sh, cand, Lt, pk[s * stride], pk[D.pack_plane + s * stride],
                                                        Pb, d, n, kdiff, kspec, shin);
             sumId = sumId + o.Id; sumIs = sumIs + o.Is; sumKd = sumKd + o.kd; sumKs = sumKs + o.ks;
         }

@@ -77,8 +77,9 @@ struct CertifyCheck {
     const Dev* D;
     const ShadowSphere* s_sh;
     uint64_t within;       // spheres the hit lies inside: met by every sample
-    const double* pk64;    // the hit's first pair of uniforms in the float64 sample buffer
+    const double* pk64;    // the hit's first angle uniform in the float64 sample buffer
     int64_t stride64;      // doubles from one sample to the next
+    int64_t plane64;       // doubles from an angle uniform to its radius uniform
     V3 Pb, lpos, xh, yh;
     double radius;
 };
@@ -86,7 +87,7 @@ struct CertifyCheck {
 // undecided spheres have their bit in `unsure` and are skipped) differs from the float64 decision of
 // the reference's arithmetic for sample s.
 __device__ __noinline__ unsigned certify_mismatches(const CertifyCheck& ck, int s, uint64_t hit, uint64_t unsure) {
-    const double u_theta = ck.pk64[s * ck.stride64], u_rad = ck.pk64[s * ck.stride64 + 1];
+    const double u_theta = ck.pk64[s * ck.stride64], u_rad = ck.pk64[ck.plane64 + s * ck.stride64];
     const double theta = u_theta * 6.283185307179586;
     const double rad = sqrt(u_rad) * ck.radius;
     double sn, cs;
@@ -460,8 +461,9 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
             CertifyCheck ck{};
             if constexpr (CHECK) {
                 ck.D = &D; ck.s_sh = s_sh; ck.within = within;
-                ck.pk64 = D.packed + 2 * (D.pack_base[l] + (active ? e : total - 1));
-                ck.stride64 = 2 * D.pack_E;
+                ck.pk64 = D.packed + D.pack_base[l] + (active ? e : total - 1);
+                ck.stride64 = D.pack_E;
+                ck.plane64 = D.pack_plane;
                 ck.Pb = Pb; ck.lpos = lpos;
                 ck.xh = {sc->lights[l].x_hat[0], sc->lights[l].x_hat[1], sc->lights[l].x_hat[2]};
                 ck.yh = {sc->lights[l].y_hat[0], sc->lights[l].y_hat[1], sc->lights[l].y_hat[2]};

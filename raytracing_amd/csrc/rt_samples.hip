@@ -70,7 +70,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, 
                 jj += D.sample_global[2 * KL + at];
             }
             if (off + 2 * N * h <= a || off >= b) continue;
-            double* dst = D.packed + 2 * (D.pack_base[l] + e);
+            double* dst = D.packed + D.pack_base[l] + e;
             for (int part = 0; part < 2; ++part) {
                 const int64_t first = off + (int64_t)part * N * h + jj;     // stream position of row 0
                 int64_t s0 = first >= a ? 0 : (a - first + h - 1) / h;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, 
                     const int64_t pos = first + s * h;
                     if (pos >= b) break;
                     const double u = chunk(pos - a);
-                    dst[2 * s * E + part] = u;
+                    dst[part * D.pack_plane + s * E] = u;
                 }
             }
         }
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, 
 // float.  The light point of a sample is then position + radius * (x * x_hat + y * y_hat).
 // Output layout: see Dev::packed32.  One thread per (tile, pair of samples, entry of the tile); slots
 // beyond the shading list or the sample count hold the disk's centre.
-__global__ __launch_bounds__(BLOCK) void k_disk_points(const double* __restrict__ pairs /* the light's first pair */, int64_t E, int N,
+__global__ __launch_bounds__(BLOCK) void k_disk_points(const double* __restrict__ angles /* the light's first angle uniform */,
+                                                       int64_t plane /* doubles from an angle to its radius uniform */, int64_t E, int N,
                                                        float4* __restrict__ points /* the light's first float4 */) {
     const int NP = (N + 1) >> 1;
     const int64_t n = ((E + TILE - 1) / TILE) * NP * TILE;
@@ -105,10 +106,10 @@ __global__ __launch_bounds__(BLOCK) void k_disk_points(const double* __restrict_
             for (int k = 0; k < 2; ++k) {
                 const int s = 2 * p + k;
                 if (s >= N) break;
-                const double2 u = reinterpret_cast<const double2*>(pairs)[s * E + e];
+                const double u_angle = angles[s * E + e], u_radius = angles[plane + s * E + e];
                 double sn, cs;
-                sincospi(2.0 * u.x, &sn, &cs);
-                const double rad = sqrt(u.y);
+                sincospi(2.0 * u_angle, &sn, &cs);
+                const double rad = sqrt(u_radius);
                 x[k] = (float)(rad * cs);
                 y[k] = (float)(rad * sn);
             }
@@ -128,10 +129,12 @@ __global__ __launch_bounds__(BLOCK) void k_disk_points(const double* __restrict_
 //   raw[i]      receives x[raw_first + i] for 0 <= i < raw_n (untempered)
 //   generates until *gen_end >= max(raw_first + raw_n, gen_until)
 //
-// Streams: the word sequence is cut into streams of L = 2^ell words; stream t covers the
-// absolute word indices [t L, (t+1) L] (one word of overlap, a value may be built from the
-// last word of one stream and the first of the next) and has its own ring and counter.
-// Stream 0 starts from the caller's key block, the others from windows k_mt_jump made.
+// Streams: the word sequence is cut into streams of L = 2^ell words; stream t has its own ring
+// and counter and starts from the window x[t L .. t L + 623]: the caller's key block for stream
+// 0, windows k_mt_jump made for the others.  The first word of such a window is only good in
+// its top bit, so stream t > 0 delivers the words [t L + 1, (t+1) L + 1] and stream 0 the words
+// [0, L + 1]: two words of overlap, so that a value built from the last word of one stream and
+// the first of the next is whole in one of them.
 constexpr int MT_N = 624, MT_M = 397, MT_STEP = MT_N - MT_M, MT_RING = 2048;
 __device__ __forceinline__ uint32_t mt_twist(uint32_t lo, uint32_t hi) {
     const uint32_t y = (lo & 0x80000000u) | (hi & 0x7fffffffu);
@@ -149,8 +152,8 @@ __global__ __launch_bounds__(256) void k_mt_generate(uint32_t* rings, long long*
     uint32_t* ring_g = rings + (size_t)t * MT_RING;
     for (int i = tid; i < MT_RING; i += 256) ring[i] = ring_g[i];
     const long long g0 = gen_ends[t];
-    const long long raw_first = (long long)t << ell;
-    long long raw_end = ((long long)(t + 1) << ell) + 1;
+    const long long raw_first = ((long long)t << ell) + (t > 0 ? 1 : 0);
+    long long raw_end = ((long long)(t + 1) << ell) + 2;
     if (raw_end > w_end) raw_end = w_end;
     if (!raw || raw_end < raw_first) raw_end = raw_first;
     const long long raw_n = raw_end - raw_first;
@@ -192,27 +195,25 @@ __global__ __launch_bounds__(256) void k_mt_generate(uint32_t* rings, long long*
 }
 
 // Jump-ahead.  Workgroup blockIdx.x makes the start window of stream t = blockIdx.x + 1:
-// the window at word index t L - 1, reached from the base window (index L - 1, taken from
-// ring `base_ring` whose counter is base_end) by applying, for every set bit b of t - 1, the
+// the window at word index t L, reached from the caller's key block (the window at index 0, in
+// ring 0, which must not have generated yet) by applying, for every set bit b of t, the
 // polynomial x^(L 2^b) mod phi:  new window word j = XOR over set coefficients i of s[i + j],
 // s the sequence generated from the current window.  The low 31 bits of the new window's
-// first word are not meaningful (nothing reads them: that word belongs to the previous
-// stream).  polys: [n_polys][624] coefficient words, polys[b] = x^(L 2^b) mod phi.
+// first word are not meaningful (nothing reads them: the previous stream delivers that
+// word).  polys: [n_polys][624] coefficient words, polys[b] = x^(L 2^b) mod phi.
 constexpr int MTJ_RING = 4096, MTJ_CHUNK = 8 * MT_STEP;   // coefficients consumed per round
-__global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen_ends, int base_ring, long long base_end,
-                                                 const uint32_t* polys, int n_polys, int ell) {
+__global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen_ends, const uint32_t* polys, int n_polys, int ell) {
     __shared__ uint32_t xs[MTJ_RING];     // s[i] at slot i & 4095
     __shared__ uint32_t coef[MT_N];
     __shared__ uint32_t win[MT_N];
     const int tid = threadIdx.x;
     const int t = blockIdx.x + 1;
     const long long L = 1ll << ell;
-    // base window = x[L-1 .. L+622]
-    for (int j = tid; j < MT_N; j += 640) win[j] = rings[(size_t)base_ring * MT_RING + ((L - 1 + j) & (MT_RING - 1))];
-    (void)base_end;
+    // base window = x[0 .. 623]
+    for (int j = tid; j < MT_N; j += 640) win[j] = rings[j];
     __syncthreads();
     for (int b = 0; b < n_polys; ++b) {
-        if (!(((unsigned)(t - 1) >> b) & 1u)) continue;      // uniform
+        if (!(((unsigned)t >> b) & 1u)) continue;      // uniform
         for (int j = tid; j < MT_N; j += 640) {
             xs[j] = win[j];
             coef[j] = polys[(size_t)b * MT_N + j];
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen
         if (tid < MT_N) win[tid] = acc;
         __syncthreads();
     }
-    // the stream's ring: window word j is x[t L - 1 + j]
-    const long long first = (long long)t * L - 1;
+    // the stream's ring: window word j is x[t L + j]
+    const long long first = (long long)t * L;
     for (int j = tid; j < MT_N; j += 640) rings[(size_t)t * MT_RING + ((first + j) & (MT_RING - 1))] = win[j];
     if (tid == 0) gen_ends[t] = first + MT_N;
 }
