@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = (nt + NW - 1) / NW;                  // tiles per wave (same for every wave)
+    const int q = tiles_per_wave(nt);
     const int wid = blockIdx.x * WPB + wave;
     const int t_first = wid * q;
     const int S = D.S;
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = max(1, (nt + NW - 1) / NW);
+    const int q = tiles_per_wave(nt);
 
     // 1. exclusive scan of the per-workgroup totals (stored counter-major), one wave per
     //    counter; every lane owns a run of consecutive entries and has all its loads in flight
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(BLOCK) void k_link(Dev D, int level) {
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = (nt + NW - 1) / NW;
+    const int q = tiles_per_wave(nt);
     const int wid = blockIdx.x * WPB + wave;
     const int t_begin = wid * q;
     const int t_end = min(nt, t_begin + q);

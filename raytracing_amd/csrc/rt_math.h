@@ -115,6 +115,15 @@ __device__ __forceinline__ v2f cull_test(const CullPair& p, float ox, float oy, 
     return vfma(-t, t, p2);
 }
 
+// Tiles per wave of a level with nt tiles: every wave of the fixed grid owns a contiguous run of this
+// many tiles (the same number in every kernel that walks the level, so that a tile's running counters
+// are found again).  A run is never shorter than RT_MIN_TILES_PER_WAVE: on a small level fewer waves
+// work, each with a filled software pipeline and one staging of the tables for more tiles.
+#ifndef RT_MIN_TILES_PER_WAVE
+#define RT_MIN_TILES_PER_WAVE 8
+#endif
+__device__ __forceinline__ int tiles_per_wave(int nt) { return max((nt + NW - 1) / NW, RT_MIN_TILES_PER_WAVE); }
+
 constexpr int CAND_MAX = 16;   // survivors a lane collects before the wave tests them
 // Number of set bits of a wave ballot below the calling lane.
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {
