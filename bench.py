@@ -1,8 +1,8 @@
 """Benchmark of the ray-tracing hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 3840 --height 2160]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config examples|1080p|spot|many|8k] [--width .. --height ..]
 
-Workload: the reference's example_1..4 scenes at 3840x2160 (the resolution
+Workload (--config examples, the default): the reference's example_1..4 scenes at 3840x2160 (the resolution
 the headline metric is quoted on), depths (3, 5), example_4 with 30 disk
 samples per hit drawn from NumPy's stream seeded with 0.  One *step* renders
 all four frames: geometry of all bounce levels, lighting/shading and the
@@ -35,6 +35,13 @@ frames (the small-batch rule needs whole-image sizes); the float64 image tiles
 of a step are gathered on rank 0 while the next step is computed (two output
 buffers), all of them before the timed region ends.
 
+Other configurations (same JSON line, same timed regions):
+  1080p  example_1..4 at 1920x1080
+  spot   a directional disk light with 64 samples per hit over a ground and a mirror ball, one frame per
+         easing mode (linear, quadratic, cubic, exponential), 3840x2160 - soft-shadow heavy
+  many   4096 random spheres (70 % glass) over a ground, point light, 3840x2160 - intersection bound
+  8k     example_4 at 7680x4320 - the frame the multi-GPU scaling target is quoted on
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -50,6 +57,13 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 SCENES = ["example_1", "example_2", "example_3", "example_4"]
+CONFIGS = {
+    "examples": (SCENES, 3840, 2160),
+    "1080p": (SCENES, 1920, 1080),
+    "spot": (["spot:linear", "spot:quadratic", "spot:cubic", "spot:exponential"], 3840, 2160),
+    "many": (["many:4096"], 3840, 2160),
+    "8k": (["example_4"], 7680, 4320),
+}
 FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X vector FP32 with packed FMA (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (half the packed-FP32 figure)
 HBM_PEAK_GBS = 8000.0
@@ -61,7 +75,10 @@ F_ISECT, F_HIT, F_LIGHT, F_SHADOW = 22, 100, 50, 24
 def cpu_baseline(seconds_budget=25.0):
     """Time the NumPy float64 oracle on this host: example_1-3 at 800x800 (about 15 s of
     CPU work; the oracle's throughput does not depend on the image size) as long as
-    the budget allows."""
+    the budget allows.  The oracle is a restatement, not the reference: it gathers by sphere
+    index and skips the reference's temporaries, and runs about three times as fast as the
+    reference itself did on the development container (0.56-0.68 Mrays/s on example_1-3);
+    example_4 (30 shadow rays per hit) is left out of the sample."""
     from oracle import numpy_oracle
     from raytracing_amd.Scenes.scenes import build_scene
     rays, spent, used = 0, 0.0, []
@@ -78,24 +95,26 @@ def cpu_baseline(seconds_budget=25.0):
     return {"value": rays / spent / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
             "sample": f"NumPy float64 oracle, {'+'.join(used)} at 800x800, {rays} rays in {spent:.1f} s "
                       f"(NumPy elementwise code is single-threaded; BLAS threads setting {threads or 'default'}, "
-                      f"host has {os.cpu_count()} logical CPUs)"}
+                      f"host has {os.cpu_count()} logical CPUs); the oracle is about 3x as fast as the reference's own "
+                      f"code (0.56-0.68 Mrays/s measured on these scenes on another host); example_4 is not in the sample"}
 
 
-def measured_traffic(kernel, args, world):
-    """HBM bytes per launch of `kernel` from the newest committed PMC measurement of this same
-    workload (profiles/rNN/pmc_traffic.json, made by tools/pmc_traffic.py); None when the
-    workload differs from the measured one."""
+def measured_counters(kernel, args, world, field, pattern="pmc_traffic*.json"):
+    """Per-launch mean of `field` for `kernel` from the newest committed counter measurement of this
+    same workload (profiles/rNN/pmc_traffic*.json: HBM bytes, made by tools/pmc_traffic.py;
+    profiles/rNN/pmc_flops*.json: executed floating-point operations, made by tools/pmc_flops.py);
+    None when no measurement of this workload is committed."""
     import glob
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", pattern)), reverse=True):
         with open(path) as f:
             rec = json.load(f)
         w = rec["workload"]
         if (w["scenes"] == list(args.scenes) and w["width"] == args.width and w["height"] == args.height
                 and w["precision"] == args.precision and w["n_gpus"] == world):
-            names = [k for k in rec["kernels"] if k.split("<")[0] == kernel]
+            names = [k for k in rec["kernels"] if k.split("<")[0] == kernel and field in rec["kernels"][k]]
             if names:
                 n = sum(rec["kernels"][k]["launches"] for k in names)
-                return sum(rec["kernels"][k]["total"] * rec["kernels"][k]["launches"] for k in names) / n
+                return sum(rec["kernels"][k][field] * rec["kernels"][k]["launches"] for k in names) / n
     return None
 
 
@@ -165,9 +184,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--scenes", nargs="*", default=SCENES)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="examples")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--scenes", nargs="*", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["mixed", "f64"], default="mixed")
     ap.add_argument("--frames", choices=["overlapped", "sequential"], default="overlapped",
@@ -179,6 +199,11 @@ def main():
 
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    cfg_scenes, cfg_w, cfg_h = CONFIGS[args.config]
+    custom = args.scenes is not None or args.width is not None or args.height is not None
+    args.scenes = list(cfg_scenes) if args.scenes is None else args.scenes
+    args.width = cfg_w if args.width is None else args.width
+    args.height = cfg_h if args.height is None else args.height
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: this process becomes the launcher
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -304,59 +329,97 @@ def main():
     #   k_trace   reads link (4 B) + parent info, hit point, direction (52 B) per non-primary ray,
     #             writes info (4 B) per ray, 48 B per stored hit record, 16 B per live hit and the
     #             per-tile counters (52 B per 64 rays);   FLOPs 22 per (ray, sphere) + 100 per hit
-    #   k_surface reads 52 B per shaded hit + 16 B per disk-light sample, writes 24 B per shaded hit;
-    #             FLOPs (50 + 24 * spheres) per light sample
+    #   k_surface reads 52 B per shaded hit and writes 24 B; per disk-light sample 8 B (the float32 pass
+    #             reads the sample's point of the unit disk as two floats) or 16 B (float64 pass: two
+    #             uniforms);   FLOPs (50 + 24 * spheres) per light sample
+    # Executed floating-point operations (what the instruction counters saw, per launch) come from the
+    # committed counter passes of the same workload when there are any (profiles/rNN/pmc_flops*.json).
     local = [job.local_stats() for job in jobs]
     sec = {k: v["ms"] * 1e-3 / args.steps for k, v in prof.items()}
     trace_bytes = sum(56 * (s["rays"] - s["pixels"]) + (4 + 52 / 64) * s["rays"] + 48 * s["stored_records"]
                       + 16 * s["live_hits"] for s in local)
     trace_flops = sum(F_ISECT * s["rays"] * s["spheres"] + F_HIT * s["hits"] for s in local)
+    mixed = all(job.precision == "mixed" for job in jobs)
+    few_spheres = all(s["spheres"] <= 64 for s in local)      # the float32 sample pass and the LDS sphere loop apply
+    float32_samples = mixed and few_spheres
     disk_samples = sum(s["shaded_samples"] - s["shaded_hits"] * sum(1 for k, _ in s["lights"] if k == 0)
                        for s in local if any(k != 0 for k, _ in s["lights"]))
-    surf_bytes = sum(76 * s["shaded_hits"] for s in local) + 16 * disk_samples
+    surf_bytes = sum(76 * s["shaded_hits"] for s in local) + (8 if float32_samples else 16) * disk_samples
     surf_flops = sum((F_LIGHT + F_SHADOW * s["spheres"]) * s["shaded_samples"] for s in local)
-    mixed = all(job.precision == "mixed" for job in jobs)
+
+    def executed(kind):
+        """Executed FLOPs of one kernel kind per launch, split by precision, and the time the vector
+        units need for them at their peaks (None without a counter pass of this workload)."""
+        f32 = measured_counters("k_" + kind, args, world, "flop_f32", "pmc_flops*.json")
+        f64 = measured_counters("k_" + kind, args, world, "flop_f64", "pmc_flops*.json")
+        if f32 is None or f64 is None:
+            return None
+        return {"flop_f32_per_launch": f32, "flop_f64_per_launch": f64,
+                "lanes_per_valu_instruction": measured_counters("k_" + kind, args, world, "lanes_per_valu", "pmc_flops*.json"),
+                "valu_seconds_at_peak": f32 / (FP32_VALU_PEAK_TFLOPS * 1e12) + f64 / (FP64_VALU_PEAK_TFLOPS * 1e12)}
 
     def roof(kind, bound, work, peak, unit, extra):
         t = sec.get(kind, 0.0)
         launches = prof[kind]["launches"] / args.steps if kind in prof else 0
         if not t or not launches:
             return None
-        achieved = work / t / (1e9 if unit == "GB/s" else 1e12)
-        r = {"kernel": "k_" + kind, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-             "frac": achieved / peak, "traffic": measured_traffic("k_" + kind, args, world),
-             "algorithmic_per_launch": work / launches, "launches_per_step": launches,
-             "avg_launch_ms": t * 1e3 / launches, "work_per_step": work}
+        ex = executed(kind)
+        r = {"kernel": "k_" + kind, "bound": bound, "unit": unit, "launches_per_step": launches, "avg_launch_ms": t * 1e3 / launches,
+             "traffic": measured_counters("k_" + kind, args, world, "total")}
+        if bound == "valu" and ex is not None:
+            # executed operations of both precisions against the time the vector units need for them
+            flops = (ex["flop_f32_per_launch"] + ex["flop_f64_per_launch"]) * launches
+            r.update({"achieved": flops / t / 1e12, "peak": flops / (ex["valu_seconds_at_peak"] * launches) / 1e12,
+                      "model": "executed FLOPs (instruction counters), peak = mix of the FP32 and FP64 vector peaks for this instruction mix",
+                      "work_per_step": flops, "algorithmic_flops_per_step": work})
+        else:
+            r.update({"achieved": work / t / (1e9 if unit == "GB/s" else 1e12), "peak": peak, "work_per_step": work,
+                      "algorithmic_per_launch": work / launches})
+        r["frac"] = r["achieved"] / r["peak"]
+        if ex is not None:
+            r["executed"] = ex
+            r["valu_frac"] = ex["valu_seconds_at_peak"] * launches / t
         r.update(extra)
         return r
 
     rooflines = {
-        "trace": roof("trace", "hbm", trace_bytes, HBM_PEAK_GBS, "GB/s",
-                      {"model": "algorithmic bytes", "flops_per_step": trace_flops, "dtype": "f64"}),
-        "surface": roof("surface", "valu", surf_flops, FP32_VALU_PEAK_TFLOPS if mixed else FP64_VALU_PEAK_TFLOPS,
-                        "TFLOP/s", {"model": "algorithmic FLOPs", "bytes_per_step": surf_bytes,
-                                    "dtype": "f32 samples, f64 decisions re-checked" if mixed else "f64"}),
+        "trace": (roof("trace", "hbm", trace_bytes, HBM_PEAK_GBS, "GB/s",
+                       {"model": "algorithmic bytes", "flops_per_step": trace_flops, "dtype": "f64"}) if few_spheres else
+                  roof("trace", "valu", trace_flops, FP32_VALU_PEAK_TFLOPS, "TFLOP/s",
+                       {"dtype": "f32 screening through the sphere hierarchy, f64 decisions",
+                        "note": "without a counter pass the figure is the brute-force model of 22 FLOP per (ray, sphere), "
+                                "most of which the hierarchy never executes"})),
+        "surface": (roof("surface", "hbm", surf_bytes, HBM_PEAK_GBS, "GB/s",
+                         {"model": "algorithmic bytes", "flops_per_step_model": surf_flops,
+                          "dtype": "f32 samples, f64 decisions re-checked"}) if float32_samples and disk_samples else
+                    roof("surface", "valu", surf_flops, FP64_VALU_PEAK_TFLOPS, "TFLOP/s",
+                         {"bytes_per_step": surf_bytes, "dtype": "f64"})),
     }
+    for r in rooflines.values():
+        if r is not None and "model" not in r:
+            r["model"] = "algorithmic FLOPs"
     dominant = max((k for k in rooflines if rooflines[k]), key=lambda k: sec.get(k, 0.0), default=None)
     roofline = rooflines.get(dominant)
 
     out = {
-        "metric": "Mrays/s (primary+secondary) at 3840x2160 example scenes",
+        "metric": ("Mrays/s (primary+secondary) at 3840x2160 example scenes" if args.config == "examples" and not custom else
+                   f"Mrays/s (primary+secondary), {'+'.join(args.scenes)} at {W}x{H}"),
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "ms_per_step_frames_sequential": elapsed_seq / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{'+'.join(args.scenes)} at {W}x{H}, depths (3,5), example_4 with 30 disk samples/hit "
-                               f"(seed 0); one step = all frames, geometry + shading",
+        "config": {"workload": f"{'+'.join(args.scenes)} at {W}x{H}, depths (3,5), disk-light samples from NumPy's stream "
+                               f"seeded with 0 (example_4: 30 per hit, spot: 64); one step = all frames, geometry + shading",
+                   "name": "custom" if custom else args.config, "scenes": list(args.scenes), "width": W, "height": H,
                    "rays_per_step": rays, "hits_per_step": hits, "shadow_rays_per_step": shadow_rays,
                    "rows_split": "contiguous cost-balanced row blocks" if world > 1 else "none",
                    "frames": args.frames,
                    "issue": ("frames one after the other, kernel by kernel" if serial else
                              ("HIP graph" if frames.graphs is not None else "kernel by kernel") +
                              (", one all-reduce per bounce level, tiles travel during the next step" if frames.pipelined else "")),
-                   "precision": ("f64 everywhere except the disk-light samples of example_4: f32 with certified "
-                                 "shadow decisions, f64 re-evaluation of uncertified hits") if mixed else "f64 everywhere"},
+                   "precision": ("f64 everywhere except disk-light samples: f32 with certified "
+                                 "shadow decisions, f64 re-evaluation of uncertified hits") if float32_samples else "f64 everywhere"},
         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
         "setup_s": setup_s,
         "end_to_end_ms_per_frame": end_to_end,
