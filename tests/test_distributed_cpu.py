@@ -170,3 +170,29 @@ def test_two_ranks_gather_8bit_tiles(tmp_path):
     img = np.load(out)
     assert img.dtype == np.uint8 and img.shape == (90, 160, 3)
     assert (img == quantise(g["example_2_image"])).all()
+
+
+def _worker_too_many_ranks(rank, world, port, out_dir):
+    _watchdog(120)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r = ShardedRenderer(build_scene("example_2", 16, 1), None, Comm(dist.group.WORLD), CpuContext())
+        try:
+            r.choose_rows()
+            verdict = "no error"
+        except ValueError as exc:
+            verdict = str(exc)
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write(verdict)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_more_ranks_than_rows_is_refused_on_every_rank(tmp_path):
+    """A rank without rows would still have to take part in every exchange; the renderer refuses the
+    split on all ranks before the first collective, so none is left waiting for the others."""
+    mp.spawn(_worker_too_many_ranks, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        assert "every rank needs at least one row" in open(tmp_path / f"rank{rank}.txt").read()
