@@ -656,13 +656,16 @@ def test_benchmark_size_properties(name):
 
 @pytest.mark.gpu
 def test_hierarchy_matches_plain_screening_at_full_size():
-    """The 4096-sphere scene at 3840x2160 (482 M rays): with and without the hierarchy the frame is
-    bit for bit the same."""
+    """The 4096-sphere scene at 3840x2160 (482 M rays): the search through the bounding-sphere hierarchy and
+    the plain screening of every (ray, sphere) pair - two different ways to the candidates of the float64
+    test - give the same frame bit for bit and the same ray, hit and shaded-hit counts.  (The pin of this
+    scene to the reference is the 64x36 golden, test_many_spheres_4096_through_the_hierarchy: the
+    reference needs 290 s for that size.)"""
     from raytracing_amd.flatten import flatten_scene
     flat = flatten_scene(synthetic.many_spheres_scene(4096, 3840, 2160))
     out = _with_and_without_hierarchy(flat, 3840, 2160)
     assert out["1"][1:] == out["0"][1:]
-    assert out["1"][1] == 482_185_288 and out["1"][2] == 376_397_367      # as measured when the scene was first rendered
+    assert out["1"][1] > 58 * 3840 * 2160 * 0.95      # the reference traces 58.3 rays per pixel on this scene at 64x36
     assert np.array_equal(out["1"][0], out["0"][0])
 
 
