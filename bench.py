@@ -287,8 +287,11 @@ def main():
     elapsed_seq = max_over_ranks(time.perf_counter() - t0)
 
     prof = {}
+    prof_by_job = []
     for job in jobs:
-        for kind, rec in job.profile(reset=False).items():
+        mine = job.profile(reset=False)
+        prof_by_job.append(mine)
+        for kind, rec in mine.items():
             acc = prof.setdefault(kind, {"ms": 0.0, "launches": 0})
             acc["ms"] += rec["ms"]
             acc["launches"] += rec["launches"]
@@ -341,31 +344,39 @@ def main():
     trace_flops = sum(F_ISECT * s["rays"] * s["spheres"] + F_HIT * s["hits"] for s in local)
     mixed = all(job.precision == "mixed" for job in jobs)
     few_spheres = all(s["spheres"] <= 64 for s in local)      # the float32 sample pass and the LDS sphere loop apply
-    float32_samples = mixed and few_spheres
-    disk_samples = sum(s["shaded_samples"] - s["shaded_hits"] * sum(1 for k, _ in s["lights"] if k == 0)
-                       for s in local if any(k != 0 for k, _ in s["lights"]))
-    surf_bytes = sum(76 * s["shaded_hits"] for s in local) + (8 if float32_samples else 16) * disk_samples
-    surf_flops = sum((F_LIGHT + F_SHADOW * s["spheres"]) * s["shaded_samples"] for s in local)
+    # frames whose lighting runs in the float32 sample pass (k_surface_mixed) and the others (k_surface, float64)
+    sampled = [any(k != 0 for k, _ in s["lights"]) and mixed and s["spheres"] <= 64 for s in local]
+    float32_samples = any(sampled)
 
-    def executed(kind):
-        """Executed FLOPs of one kernel kind per launch, split by precision, and the time the vector
+    def surface_work(which):
+        picked = [(s, p) for s, p, m in zip(local, prof_by_job, sampled) if m == which]
+        disk = sum(s["shaded_samples"] - s["shaded_hits"] * sum(1 for k, _ in s["lights"] if k == 0)
+                   for s, _ in picked if any(k != 0 for k, _ in s["lights"]))
+        return {"bytes": sum(76 * s["shaded_hits"] for s, _ in picked) + (8 if which else 16) * disk,
+                "flops": sum((F_LIGHT + F_SHADOW * s["spheres"]) * s["shaded_samples"] for s, _ in picked),
+                "seconds": sum(p.get("surface", {"ms": 0.0})["ms"] for _, p in picked) * 1e-3 / args.steps,
+                "launches": sum(p.get("surface", {"launches": 0})["launches"] for _, p in picked) / args.steps}
+
+    def executed(kernel):
+        """Executed FLOPs of one kernel per launch, split by precision, and the time the vector
         units need for them at their peaks (None without a counter pass of this workload)."""
-        f32 = measured_counters("k_" + kind, args, world, "flop_f32", "pmc_flops*.json")
-        f64 = measured_counters("k_" + kind, args, world, "flop_f64", "pmc_flops*.json")
+        f32 = measured_counters(kernel, args, world, "flop_f32", "pmc_flops*.json")
+        f64 = measured_counters(kernel, args, world, "flop_f64", "pmc_flops*.json")
         if f32 is None or f64 is None:
             return None
         return {"flop_f32_per_launch": f32, "flop_f64_per_launch": f64,
-                "lanes_per_valu_instruction": measured_counters("k_" + kind, args, world, "lanes_per_valu", "pmc_flops*.json"),
+                "lanes_per_valu_instruction": measured_counters(kernel, args, world, "lanes_per_valu", "pmc_flops*.json"),
                 "valu_seconds_at_peak": f32 / (FP32_VALU_PEAK_TFLOPS * 1e12) + f64 / (FP64_VALU_PEAK_TFLOPS * 1e12)}
 
-    def roof(kind, bound, work, peak, unit, extra):
-        t = sec.get(kind, 0.0)
-        launches = prof[kind]["launches"] / args.steps if kind in prof else 0
+    def roof(kind, bound, work, peak, unit, extra, kernel=None, t=None, launches=None):
+        kernel = kernel or "k_" + kind
+        t = sec.get(kind, 0.0) if t is None else t
+        launches = (prof[kind]["launches"] / args.steps if kind in prof else 0) if launches is None else launches
         if not t or not launches:
             return None
-        ex = executed(kind)
-        r = {"kernel": "k_" + kind, "bound": bound, "unit": unit, "launches_per_step": launches, "avg_launch_ms": t * 1e3 / launches,
-             "traffic": measured_counters("k_" + kind, args, world, "total")}
+        ex = executed(kernel)
+        r = {"kernel": kernel, "bound": bound, "unit": unit, "launches_per_step": launches, "avg_launch_ms": t * 1e3 / launches,
+             "traffic": measured_counters(kernel, args, world, "total")}
         if bound == "valu" and ex is not None:
             # executed operations of both precisions against the time the vector units need for them
             flops = (ex["flop_f32_per_launch"] + ex["flop_f64_per_launch"]) * launches
@@ -389,16 +400,21 @@ def main():
                        {"dtype": "f32 screening through the sphere hierarchy, f64 decisions",
                         "note": "without a counter pass the figure is the brute-force model of 22 FLOP per (ray, sphere), "
                                 "most of which the hierarchy never executes"})),
-        "surface": (roof("surface", "hbm", surf_bytes, HBM_PEAK_GBS, "GB/s",
-                         {"model": "algorithmic bytes", "flops_per_step_model": surf_flops,
-                          "dtype": "f32 samples, f64 decisions re-checked"}) if float32_samples and disk_samples else
-                    roof("surface", "valu", surf_flops, FP64_VALU_PEAK_TFLOPS, "TFLOP/s",
-                         {"bytes_per_step": surf_bytes, "dtype": "f64"})),
     }
+    w32, w64 = surface_work(True), surface_work(False)
+    # the float32 sample pass streams 8 bytes per sample and is bound by HBM; the float64 pass by the vector units
+    rooflines["surface_mixed"] = roof("surface", "hbm", w32["bytes"], HBM_PEAK_GBS, "GB/s",
+                                      {"model": "algorithmic bytes", "flops_per_step_model": w32["flops"],
+                                       "dtype": "f32 samples, f64 decisions re-checked"},
+                                      kernel="k_surface_mixed", t=w32["seconds"], launches=w32["launches"])
+    rooflines["surface"] = roof("surface", "valu", w64["flops"], FP64_VALU_PEAK_TFLOPS, "TFLOP/s",
+                                {"bytes_per_step": w64["bytes"], "dtype": "f64"},
+                                kernel="k_surface", t=w64["seconds"], launches=w64["launches"])
     for r in rooflines.values():
         if r is not None and "model" not in r:
             r["model"] = "algorithmic FLOPs"
-    dominant = max((k for k in rooflines if rooflines[k]), key=lambda k: sec.get(k, 0.0), default=None)
+    dominant = max((k for k in rooflines if rooflines[k]),
+                   key=lambda k: rooflines[k]["avg_launch_ms"] * rooflines[k]["launches_per_step"], default=None)
     roofline = rooflines.get(dominant)
 
     out = {
