@@ -99,18 +99,20 @@ def cpu_baseline(seconds_budget=25.0):
                       f"code (0.56-0.68 Mrays/s measured on these scenes on another host); example_4 is not in the sample"}
 
 
-def measured_counters(kernel, args, world, field, pattern="pmc_traffic*.json"):
+def measured_counters(kernel, args, world, field, pattern="pmc_traffic*.json", precision=None):
     """Per-launch mean of `field` for `kernel` from the newest committed counter measurement of this
     same workload (profiles/rNN/pmc_traffic*.json: HBM bytes, made by tools/pmc_traffic.py;
     profiles/rNN/pmc_flops*.json: executed floating-point operations, made by tools/pmc_flops.py);
-    None when no measurement of this workload is committed."""
+    None when no measurement of this workload is committed.  `precision` is what the workload ran in
+    ("mixed" when some frame's samples went through the float32 pass, else "f64")."""
     import glob
+    precision = precision or args.precision
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", pattern)), reverse=True):
         with open(path) as f:
             rec = json.load(f)
         w = rec["workload"]
         if (w["scenes"] == list(args.scenes) and w["width"] == args.width and w["height"] == args.height
-                and w["precision"] == args.precision and w["n_gpus"] == world):
+                and w["precision"] == precision and w["n_gpus"] == world):
             names = [k for k in rec["kernels"] if k.split("<")[0] == kernel and field in rec["kernels"][k]]
             if names:
                 n = sum(rec["kernels"][k]["launches"] for k in names)
@@ -347,6 +349,7 @@ def main():
     # frames whose lighting runs in the float32 sample pass (k_surface_mixed) and the others (k_surface, float64)
     sampled = [any(k != 0 for k, _ in s["lights"]) and mixed and s["spheres"] <= 64 for s in local]
     float32_samples = any(sampled)
+    ran_in = "mixed" if float32_samples else "f64"      # how the committed counter passes name the workload
 
     def surface_work(which):
         picked = [(s, p) for s, p, m in zip(local, prof_by_job, sampled) if m == which]
@@ -360,12 +363,12 @@ def main():
     def executed(kernel):
         """Executed FLOPs of one kernel per launch, split by precision, and the time the vector
         units need for them at their peaks (None without a counter pass of this workload)."""
-        f32 = measured_counters(kernel, args, world, "flop_f32", "pmc_flops*.json")
-        f64 = measured_counters(kernel, args, world, "flop_f64", "pmc_flops*.json")
+        f32 = measured_counters(kernel, args, world, "flop_f32", "pmc_flops*.json", ran_in)
+        f64 = measured_counters(kernel, args, world, "flop_f64", "pmc_flops*.json", ran_in)
         if f32 is None or f64 is None:
             return None
         return {"flop_f32_per_launch": f32, "flop_f64_per_launch": f64,
-                "lanes_per_valu_instruction": measured_counters(kernel, args, world, "lanes_per_valu", "pmc_flops*.json"),
+                "lanes_per_valu_instruction": measured_counters(kernel, args, world, "lanes_per_valu", "pmc_flops*.json", ran_in),
                 "valu_seconds_at_peak": f32 / (FP32_VALU_PEAK_TFLOPS * 1e12) + f64 / (FP64_VALU_PEAK_TFLOPS * 1e12)}
 
     def roof(kind, bound, work, peak, unit, extra, kernel=None, t=None, launches=None):
@@ -376,7 +379,7 @@ def main():
             return None
         ex = executed(kernel)
         r = {"kernel": kernel, "bound": bound, "unit": unit, "launches_per_step": launches, "avg_launch_ms": t * 1e3 / launches,
-             "traffic": measured_counters(kernel, args, world, "total")}
+             "traffic": measured_counters(kernel, args, world, "total", precision=ran_in)}
         if bound == "valu" and ex is not None:
             # executed operations of both precisions against the time the vector units need for them
             flops = (ex["flop_f32_per_launch"] + ex["flop_f64_per_launch"]) * launches
