@@ -241,11 +241,11 @@ def main():
     def barrier():
         frames.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if group is not None:
             torch.distributed.barrier(group=group)
 
     def max_over_ranks(seconds):
-        if world == 1:
+        if group is None:
             return seconds
         on_gpu = torch.distributed.get_backend(group) == "nccl"
         t = torch.tensor([seconds], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
@@ -303,7 +303,7 @@ def main():
     # with a warm context - geometry with the count read-back, generating and packing the disk-light
     # samples from NumPy's stream state, shading, copying the float64 image to the host
     end_to_end = None
-    if world == 1:
+    if group is None:
         end_to_end = {}
         for job in jobs:
             np.random.seed(0)
@@ -321,6 +321,7 @@ def main():
     stats = [job.stats() for job in jobs]            # global (all-rank) counts per frame
     if rank != 0:
         frames.close()
+        torch.distributed.destroy_process_group()
         return
 
     rays = sum(s["rays"] for s in stats)
@@ -432,7 +433,7 @@ def main():
                                f"seeded with 0 (example_4: 30 per hit, spot: 64); one step = all frames, geometry + shading",
                    "name": "custom" if custom else args.config, "scenes": list(args.scenes), "width": W, "height": H,
                    "rays_per_step": rays, "hits_per_step": hits, "shadow_rays_per_step": shadow_rays,
-                   "rows_split": "contiguous cost-balanced row blocks" if world > 1 else "none",
+                   "rows_split": "contiguous cost-balanced row blocks" if frames.sharded else "none",
                    "frames": args.frames,
                    "issue": ("frames one after the other, kernel by kernel" if serial else
                              ("HIP graph" if frames.graphs is not None else "kernel by kernel") +
@@ -448,6 +449,8 @@ def main():
     if not args.no_cpu_baseline and world == 1:      # the host baseline is timed on single-GPU runs only
         out["cpu_baseline"] = cpu_baseline()
     frames.close()
+    if group is not None:
+        torch.distributed.destroy_process_group()
     print(json.dumps(out))
 
 

@@ -41,6 +41,13 @@ SAMPLE_CHUNK = 1 << 24
 F_ISECT, F_HIT, F_LIGHT, F_SHADOW = 22, 100, 50, 24
 
 
+def is_sharded(world, group):
+    """Does the frame go through the multi-rank path (row blocks, per-level sums, tile transfers)?
+    Yes with more than one rank; RT_SHARDED_PATH=1 also sends a process group of ONE rank through
+    it, which rehearses that path (RCCL calls included) on a box with a single GPU."""
+    return world > 1 or (group is not None and os.environ.get("RT_SHARDED_PATH") == "1")
+
+
 # ----------------------------------------------------------------------------------------------
 class Comm:
     """The handful of collectives the renderer needs, on NumPy arrays."""
@@ -50,11 +57,13 @@ class Comm:
         self.tile_group = group       # group the tile transfers run on (see separate_tile_group)
         self.device = device          # torch device the backend's tensors must live on
         self.host_staged = False      # device tensors go through host copies (gloo)
+        self.sharded = False          # the multi-rank path is taken (see is_sharded)
         if group is None:
             self.rank, self.world = 0, 1
         else:
             import torch.distributed as dist
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            self.sharded = is_sharded(self.world, group)
             if device is not None and dist.get_backend(group) != "nccl":
                 # gloo's handling of device tensors is unreliable here; small exchanges use host
                 # tensors and tiles are copied through the host
@@ -67,7 +76,7 @@ class Comm:
         return t.to(self.device) if self.device is not None else t
 
     def all_reduce_sum(self, a):
-        if self.world == 1:
+        if not self.sharded:
             return np.asarray(a)
         import torch.distributed as dist
         t = self._t(a)
@@ -78,7 +87,7 @@ class Comm:
         """In-place sum of a torch tensor over the ranks.  Device tensors with RCCL: queued behind
         the work of the current stream, nothing waits on the host.  Backends that cannot take
         device tensors: through a host copy (synchronises the current stream)."""
-        if self.world == 1:
+        if not self.sharded:
             return
         import torch.distributed as dist
         if t.is_cuda and self.host_staged:
@@ -92,7 +101,7 @@ class Comm:
         """Give the tile transfers a process group (an RCCL communicator and stream) of their
         own, so that a frame's tiles can travel while the next frame's per-level sums run.
         Collective: every rank of the group must call it."""
-        if self.world > 1 and self.tile_group is self.group:
+        if self.sharded and self.tile_group is self.group:
             import torch.distributed as dist
             ranks = dist.get_process_group_ranks(self.group)
             self.tile_group = dist.new_group(ranks=ranks, backend=dist.get_backend(self.group))
@@ -104,7 +113,7 @@ class Comm:
     def all_gather(self, a):
         """Stack every rank's array (same shape everywhere) along a new first axis."""
         a = np.asarray(a)
-        if self.world == 1:
+        if not self.sharded:
             return a[None]
         import torch
         import torch.distributed as dist
@@ -114,7 +123,7 @@ class Comm:
         return np.stack([o.cpu().numpy() for o in out])
 
     def barrier(self):
-        if self.world > 1:
+        if self.sharded:
             import torch.distributed as dist
             dist.barrier(group=self.group)
 
@@ -127,7 +136,7 @@ class Comm:
     def gather_tiles_many(self, frames):
         """gather_tiles for several frames, ``[(full, tile, bounds, width), ...]``, as one batch
         of transfers (one group call for all frames and ranks)."""
-        if self.world == 1:
+        if not self.sharded:
             return
         import torch
         import torch.distributed as dist
@@ -162,7 +171,7 @@ def init_group(n_gpus):
     GPU, RCCL).  Returns ``(rank, world, group)``; a single process gets
     ``(0, 1, None)`` without touching torch.distributed."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and os.environ.get("RT_SHARDED_PATH") != "1":
         return 0, 1, None
     import torch
     import torch.distributed as dist
@@ -265,7 +274,7 @@ class ShardedRenderer:
             # not supported: every rank raises here, before any collective, so none is left waiting
             raise ValueError(f"{self.comm.world} ranks for an image of {self.params.height} rows: "
                              "every rank needs at least one row")
-        if self.comm.world == 1:
+        if not self.comm.sharded:
             self.bounds = np.array([0, self.params.height], dtype=np.int64)
         else:
             rows, cost = self.probe_costs()
@@ -304,7 +313,7 @@ class ShardedRenderer:
 
     def trace(self):
         """Geometry phase with the per-level exchange of batch sizes."""
-        if self.comm.world == 1:
+        if not self.comm.sharded:
             self.ctx.trace_geometry()
             return
         for level in range(self.tree.n_levels):
@@ -314,7 +323,7 @@ class ShardedRenderer:
         """One bounce level: whole-image batch sizes of the level's nodes (sum over the
         ranks, the small-batch rule needs them), then the level's kernels."""
         ctx, comm = self.ctx, self.comm
-        if level > 0 and comm.world > 1:
+        if level > 0 and comm.sharded:
             if self.batch_tensor is not None:
                 # batch sizes stay on the GPU: the all-reduce is queued on the kernels' stream
                 # between two levels and (with RCCL) nothing waits on the host
@@ -357,7 +366,7 @@ class ShardedRenderer:
         l_off, l_cnt, l_total = sample_offsets(self.tree, lights, self.local_hits, self.local_beam)
         self.ctx.set_sample_layout(l_off, l_total)
         self.samples_total = l_total
-        if self.comm.world == 1:
+        if not self.comm.sharded:
             state = legacy_mt19937_state(rng) if hasattr(self.ctx, "generate_samples") else None
             if state is not None:      # MT19937 runs on the GPU; the stream is advanced as host draws would
                 key, pos = self.ctx.generate_samples(state[1], state[2])
@@ -458,7 +467,7 @@ def raytrace(scene, *, params=None, device=None, output="f64"):
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(device)
-    comm = Comm(group, torch.device("cuda", device) if world > 1 else None)
+    comm = Comm(group, torch.device("cuda", device) if is_sharded(world, group) else None)
     ctx = _native.Context(device, torch.cuda.current_stream().cuda_stream)
     try:
         return raytrace_sharded(scene, params, comm, ctx, output=output)
@@ -486,20 +495,21 @@ class FrameJob:
         self.torch = torch
         self.name = scene_name
         self.device = torch.device("cuda", device)
-        self.comm = comm if comm is not None else Comm(group, self.device if world > 1 else None)
+        sharded = is_sharded(world, group)
+        self.comm = comm if comm is not None else Comm(group, self.device if sharded else None)
         scene = build_scene(scene_name, width, height)
         params = RenderParams(width=width, height=height)
         self.stream = torch.cuda.Stream(self.device)
         self.ctx = _native.Context(device, self.stream.cuda_stream)
         self.precision = precision
         self.r = ShardedRenderer(scene, params, self.comm, self.ctx)
-        if world > 1 and batches is not None:
+        if sharded and batches is not None:
             self.r.batch_tensor, self.r.batch_slot, self.r.batch_slots = batches
-        elif world > 1 and batch_exchange_mode(group) == "device":
+        elif sharded and batch_exchange_mode(group) == "device":
             with torch.cuda.stream(self.stream):
                 self.r.batch_tensor = torch.zeros(self.r.tree.n_nodes, dtype=torch.int32, device=self.device)
         self.width, self.height = width, height
-        self.n_buffers = n_buffers if world > 1 else 1
+        self.n_buffers = n_buffers if sharded else 1
         self.fulls, self.tiles = [], []
         self.full = self.tile = None
 
@@ -515,7 +525,7 @@ class FrameJob:
             r.choose_rows()
             r0, r1 = r.my_rows
             W = self.width
-            if self.comm.world > 1:
+            if self.comm.sharded:
                 for _ in range(self.n_buffers):
                     if self.comm.rank == 0:
                         full = torch.empty((self.height * W, 3), dtype=torch.float64, device=self.device)
@@ -538,7 +548,7 @@ class FrameJob:
         with self.torch.cuda.stream(self.stream):
             r.trace()
             r.shade()
-            if self.comm.world > 1:
+            if self.comm.sharded:
                 self.comm.gather_tiles(self.full, self.tile, r.bounds, self.width)
 
     # The same step in pieces, for callers that interleave several jobs level by level: the
@@ -555,7 +565,7 @@ class FrameJob:
     def step_finish(self):
         with self.torch.cuda.stream(self.stream):
             self.r.shade()
-            if self.comm.world > 1:
+            if self.comm.sharded:
                 self.comm.gather_tiles(self.full, self.tile, self.r.bounds, self.width)
 
     def synchronize(self):
@@ -563,7 +573,7 @@ class FrameJob:
 
     def image(self):
         """Rank 0: the whole frame as a NumPy array (other ranks: their tile)."""
-        if self.comm.world == 1:
+        if not self.comm.sharded:
             return self.ctx.read_image().reshape(self.height, self.width, 3)
         self.synchronize()
         t = self.full if self.comm.rank == 0 else self.tile
@@ -612,10 +622,11 @@ class FrameSet:
         import torch
         self.torch = torch
         self.world, self.rank = world, rank
+        self.sharded = is_sharded(world, group)
         self.device = torch.device("cuda", device)
-        self.comm = Comm(group, self.device if world > 1 else None)
+        self.comm = Comm(group, self.device if self.sharded else None)
         self.use_graphs = os.environ.get("RT_STEP_GRAPH", "1") != "0"
-        self.pipelined = world > 1 and batch_exchange_mode(group) == "device"
+        self.pipelined = self.sharded and batch_exchange_mode(group) == "device"
         self.stream = torch.cuda.Stream(self.device)          # levels are joined here, collectives queue here
         self.tile_stream = torch.cuda.Stream(self.device)     # tile transfers
         F = len(scene_names)
@@ -646,7 +657,7 @@ class FrameSet:
             np.random.seed(seed)
             job.prepare()
         self.synchronize()
-        if self.use_graphs and (self.world == 1 or self.pipelined):
+        if self.use_graphs and (not self.sharded or self.pipelined):
             self.capture()
 
     # ---- issuing work -------------------------------------------------------------------------
@@ -667,7 +678,9 @@ class FrameSet:
         torch = self.torch
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(self.stream):
-            g.capture_begin(capture_error_mode="thread_local")
+            # "relaxed": calls other threads make while this one captures must not end the capture -
+            # RCCL's watchdog thread polls the events of finished collectives at any time
+            g.capture_begin(capture_error_mode="relaxed")
             try:
                 self._side_by_side(body)
             finally:
@@ -692,7 +705,7 @@ class FrameSet:
 
     def capture(self):
         try:
-            if self.world == 1:
+            if not self.sharded:
                 self.graphs = {"step": self._captured(self._whole)}
             else:
                 self.graphs = {"level": [self._captured(self._level(l)) for l in range(self.jobs[0].n_levels)],
@@ -714,7 +727,7 @@ class FrameSet:
 
     def step(self):
         torch = self.torch
-        if self.world > 1 and not self.pipelined:
+        if self.sharded and not self.pipelined:
             for level in range(self.jobs[0].n_levels):
                 for job in self.jobs:
                     job.step_level(level)
@@ -722,7 +735,7 @@ class FrameSet:
                 job.step_finish()
             return
         with torch.cuda.stream(self.stream):
-            if self.world == 1:
+            if not self.sharded:
                 self._run("step", None, self._whole)
                 return
             first = self.jobs[0].r

@@ -203,3 +203,67 @@ def test_bench_starts_its_own_ranks(tmp_path):
     g = np.load(os.path.join(GOLDEN, "images_160x90.npz"))
     want = sum(int(g[n + "_rays"][g[n + "_rays"] >= 3].sum()) for n in ("example_1", "example_2", "example_3", "example_4"))
     assert out["config"]["rays_per_step"] == want
+
+
+def test_bench_one_rank_through_the_rccl_path(tmp_path):
+    """The multi-rank path with its RCCL calls (device all-reduce between the level graphs, a
+    communicator of their own for the tile transfers, the barrier and the maximum over ranks of
+    the benchmark) on the one GPU of the box: a process group of a single rank, sent through that
+    path by RT_SHARDED_PATH=1.  Counts and throughput fields must come out as on the plain path."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RT_DIST_BACKEND", "RT_BENCH_DEVICE")}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), RT_SHARDED_PATH="1", RT_BENCH_WATCHDOG="200")
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--width", "160", "--height", "90", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert "one all-reduce per bounce level" in out["config"]["issue"] and "HIP graph" in out["config"]["issue"]
+    g = np.load(os.path.join(GOLDEN, "images_160x90.npz"))
+    want = sum(int(g[n + "_rays"][g[n + "_rays"] >= 3].sum()) for n in ("example_1", "example_2", "example_3", "example_4"))
+    assert out["config"]["rays_per_step"] == want
+
+
+def _worker_one_rank_rccl(rank, world, port, w, h, out_path):
+    _watchdog()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RT_SHARDED_PATH"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        from raytracing_amd.distributed import FrameSet
+        frames = FrameSet(SET_SCENES, w, h, device=0, rank=rank, world=world, group=dist.group.WORLD)
+        frames.prepare(seed=0)
+        assert frames.sharded and frames.pipelined and frames.graphs is not None
+        per_step = []
+        for _ in range(3):
+            frames.step()
+            per_step.append(frames.images())
+        frames.step()
+        frames.step()
+        per_step.append(frames.images())
+        np.savez(out_path, images=np.array(per_step))
+        frames.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_set_one_rank_over_rccl(tmp_path):
+    """FrameSet's multi-rank issue order (level graphs with the batch-size sums between them queued
+    on the stream by RCCL, double-buffered tiles) with device tensors and the nccl backend."""
+    g = np.load(os.path.join(GOLDEN, "images_160x90.npz"))
+    out = str(tmp_path / "set.npz")
+    mp.spawn(_worker_one_rank_rccl, args=(1, _free_port(), 160, 90, out), nprocs=1, join=True)
+    res = np.load(out)
+    for f, name in enumerate(SET_SCENES):
+        for step in range(4):
+            assert np.abs(res["images"][step, f] - g[name + "_image"]).max() <= (2e-5 if name == "example_4" else 1e-8)
+            assert np.array_equal(res["images"][step, f], res["images"][0, f])
