@@ -146,11 +146,18 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
     const int wid = blockIdx.x * WPB + wave;
     const int t_first = wid * q;
     const int S = D.S;
-    const bool block_has_work = blockIdx.x * WPB * q < nt;
+    if (blockIdx.x * WPB * q >= nt) {
+        // no tile for this workgroup (most of the grid at a deep level): its counters are zero
+        if (lane < NCNT) {
+            D.wave_off[((size_t)level * NCNT + lane) * NW + wid] = 0;
+            if (wave == WPB - 1) D.blk_tot[((size_t)level * NCNT + lane) * NB + blockIdx.x] = 0;
+        }
+        return;
+    }
 
     for (int i = tid; i < (int)(sizeof(SceneConst) / 8); i += BLOCK)
         reinterpret_cast<double*>(&s_sc)[i] = reinterpret_cast<const double*>(D.sc)[i];
-    if (block_has_work) {
+    {
         const int small_num = D.sc->small_num;
         for (int i = tid; i < nn; i += BLOCK) {
             const int k = k0 + i;
