@@ -633,7 +633,10 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
 // ---------------------------------------------------------------------------------------------
 // Tiles a wave handles per loop iteration in the bookkeeping kernels: their loads are
 // issued together so that their latencies overlap.
-constexpr int UNROLL_TILES = 4;
+#ifndef RT_LINK_TILES
+#define RT_LINK_TILES 4
+#endif
+constexpr int UNROLL_TILES = RT_LINK_TILES;
 
 // Per-node tables of one level in (dynamic) LDS for the bookkeeping kernels: tile layout,
 // first arena slot of each child node and the level-wide running value of every counter

@@ -12,9 +12,12 @@ namespace rt {
 // scenes most tiles hold none (every ray below an opaque, non-reflecting hit is traced for the
 // batch and hit counts only).  A wave therefore first reads the running count of live hits that
 // k_trace left at each of its tiles and visits only the tiles where it changes.  The tiles it
-// visits go through a two-stage software pipeline, two tiles per stage: while the colours one
-// pair selected are in flight, the info words of the next pair are requested already.
-constexpr int COMBINE_TILES = 2;
+// visits go through a two-stage software pipeline, three tiles per stage: while the colours one
+// group selected are in flight, the info words of the next group are requested already.
+#ifndef RT_COMBINE_TILES
+#define RT_COMBINE_TILES 3
+#endif
+constexpr int COMBINE_TILES = RT_COMBINE_TILES;
 struct CombineSphere {
     double tr, kr, kg, kb;   // transparency, -attenuation * absorption colour
 };
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
         return c;
     };
 
-    // One pipeline step: second set of loads for the pair `cur`, then the first set of the pair
+    // One pipeline step: second set of loads for the group `cur`, then the first set of the group
     // after it (into `nxt`), then arithmetic and stores for `cur`.
     auto step = [&](const CombineTile (&cur)[COMBINE_TILES], CombineTile (&nxt)[COMBINE_TILES]) {
         double A[COMBINE_TILES], through[COMBINE_TILES];
