@@ -421,6 +421,9 @@ def main():
                    key=lambda k: rooflines[k]["avg_launch_ms"] * rooflines[k]["launches_per_step"], default=None)
     roofline = rooflines.get(dominant)
 
+    # whole-image counts of all ranks
+    step_flops = sum(F_ISECT * st["spheres"] * st["rays"] + F_HIT * st["hits"]
+                     + (F_LIGHT + F_SHADOW * st["spheres"]) * st["shadow_rays"] for st in stats)
     out = {
         "metric": ("Mrays/s (primary+secondary) at 3840x2160 example scenes" if args.config == "examples" and not custom else
                    f"Mrays/s (primary+secondary), {'+'.join(args.scenes)} at {W}x{H}"),
@@ -445,6 +448,12 @@ def main():
         "end_to_end_ms_per_frame": end_to_end,
         "roofline": roofline,
         "rooflines": rooflines,
+        # the whole step against the vector peak, by the algorithmic FLOP model (22 per ray-sphere test, 100 per hit,
+        # 50 + 24 * spheres per light sample): most of these operations run in float64 here (half the FP32 rate)
+        "step_vs_fp32_valu_peak": {"algorithmic_flops_per_step": step_flops,
+                                   "achieved_tflops": step_flops / (ms_per_step * 1e-3) / 1e12,
+                                   "peak_tflops": FP32_VALU_PEAK_TFLOPS * world,
+                                   "frac": step_flops / (ms_per_step * 1e-3) / 1e12 / (FP32_VALU_PEAK_TFLOPS * world)},
     }
     if not args.no_cpu_baseline and world == 1:      # the host baseline is timed on single-GPU runs only
         out["cpu_baseline"] = cpu_baseline()
