@@ -6,6 +6,11 @@
 
 namespace rt {
 
+// Store of a value that nobody reads soon: goes to memory without displacing cached data that is still in use.
+template <typename T>
+__device__ __forceinline__ void stream_store(T v, T* p) { __builtin_nontemporal_store(v, p); }
+
+
 
 struct V3 {
     double x, y, z;
