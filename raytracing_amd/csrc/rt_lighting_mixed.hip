@@ -241,6 +241,12 @@ __device__ __forceinline__ void eval_pair(const float4 u, const v2f w, const boo
 // wave reads 1 KiB per pair, 16 bytes per lane.  The loads of the next batch of pairs are requested
 // before the current batch is evaluated.  Slots beyond the sample count (an odd count, a batch that
 // is not full) are evaluated with weight 0 on the data of the last pair.
+// A pair of disk points: read exactly once per frame, so as a streaming load (measured -3 % on the kernel).
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_load(const float4* p) {
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 template <int T, bool SIMPLE, bool CHECK>
 __device__ __forceinline__ void disk_samples(const float4* __restrict__ pk, const int N, const DiskHit& H, const HitSphere (&hs)[MIXED_T],
                                              const int (&idx)[MIXED_T], const DiskLightConst& L, const ShadowSphere* s_sh,
@@ -249,12 +255,12 @@ __device__ __forceinline__ void disk_samples(const float4* __restrict__ pk, cons
     const int n_batches = (NP + PAIR_BATCH - 1) / PAIR_BATCH;
     float4 cur[PAIR_BATCH], nxt[PAIR_BATCH];
 #pragma unroll
-    for (int k = 0; k < PAIR_BATCH; ++k) cur[k] = pk[(int64_t)min(k, NP - 1) * TILE];
+    for (int k = 0; k < PAIR_BATCH; ++k) cur[k] = stream_load(&pk[(int64_t)min(k, NP - 1) * TILE]);
     for (int bt = 0; bt < n_batches; ++bt) {
         // unconditional (the last batch requests the last pair again): a branch around the loads would
         // make the compiler wait for them before the batch at hand is evaluated
 #pragma unroll
-        for (int k = 0; k < PAIR_BATCH; ++k) nxt[k] = pk[(int64_t)min((bt + 1) * PAIR_BATCH + k, NP - 1) * TILE];
+        for (int k = 0; k < PAIR_BATCH; ++k) nxt[k] = stream_load(&pk[(int64_t)min((bt + 1) * PAIR_BATCH + k, NP - 1) * TILE]);
 #pragma unroll
         for (int k = 0; k < PAIR_BATCH; ++k) {
             const int s = 2 * (bt * PAIR_BATCH + k);
