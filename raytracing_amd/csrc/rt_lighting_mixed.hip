@@ -419,9 +419,6 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
                 if (lit && !ruled_out && !inside) need |= 1ull << i;
             }
             H.ps = (SIMPLE ? sc->lightf[l].ps_grey : sc->lightf[l].ps) * tr_within;
-#ifdef RT_DBG_FORCE_T0
-            need = 0;
-#endif
             int mine = __popcll(need);
             const bool too_many = mine > MIXED_T;
             if (too_many) {   // more candidates than the sample loop holds: this hit goes to the float64 re-evaluation
@@ -434,9 +431,6 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
 #pragma unroll
             for (int k = 1; k <= MIXED_T; ++k)
                 if (__ballot(mine >= k) != 0) Tn = k;
-#ifdef RT_MIXED_STATS
-            if (lane == 0 && Tn == RT_MIXED_STATS) my_mismatches += 1;   // debug build: waves with this many slots
-#endif
             HitSphere hs[MIXED_T];
             int idx[MIXED_T];
             {
@@ -478,7 +472,6 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
             SampleSums<SIMPLE> A;
             bool unsure = false;
             unsigned mismatches = 0;
-#ifndef RT_DBG_SKIP_LOOP
             switch (Tn) {
                 case 0: disk_samples<0, SIMPLE, CHECK>(pk, N, H, hs, idx, L, s_sh, A, unsure, ck, mismatches); break;
                 case 1: disk_samples<1, SIMPLE, CHECK>(pk, N, H, hs, idx, L, s_sh, A, unsure, ck, mismatches); break;
@@ -486,9 +479,6 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
                 case 3: disk_samples<3, SIMPLE, CHECK>(pk, N, H, hs, idx, L, s_sh, A, unsure, ck, mismatches); break;
                 default: disk_samples<4, SIMPLE, CHECK>(pk, N, H, hs, idx, L, s_sh, A, unsure, ck, mismatches); break;
             }
-#else
-            if constexpr (SIMPLE) A.open.x = pk[0].x + hs[0].oc.x + hs[1].C + hs[2].k0 + hs[3].len2 + H.q.x + H.nf.y + H.df.z + H.nd2 + H.sh + H.eLk;
-#endif
             if (lit) {
                 redo = redo || unsure;
                 if (CHECK && !unsure && !too_many) my_mismatches += mismatches;
