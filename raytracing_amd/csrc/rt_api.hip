@@ -155,7 +155,7 @@ struct RtContext {
     DevBuf<int32_t> node_a, node_b, node_branch, node_child, level_start;
     DevBuf<int32_t> node_n, node_nglobal, node_hits, node_beam, node_tile0, node_ntiles, lvl_ntiles, lvl_tilebase, flags;
     DevBuf<uint32_t> node_start, node_pre, tile_run, blk_tot, wave_off;
-    DevBuf<double> px, py, pz, dx, dy, dz, A, dist, cr, cg, cb;
+    DevBuf<double> px, py, pz, dx, dy, dz, A, dist, cr, cg, cb, sr, sg, sb;
     DevBuf<uint32_t> info, link, list_ray, redo_list, list_j[1 + RT_MAX_LIGHTS];
     DevBuf<uint16_t> list_node;
     DevBuf<int32_t> lvl_shade_base;
@@ -216,7 +216,7 @@ struct RtContext {
         D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p; D.wave_off = wave_off.p;
         D.flags = flags.p; D.work = work.p;
         D.px = px.p; D.py = py.p; D.pz = pz.p; D.dx = dx.p; D.dy = dy.p; D.dz = dz.p; D.A = A.p; D.dist = dist.p;
-        D.info = info.p; D.link = link.p; D.cr = cr.p; D.cg = cg.p; D.cb = cb.p;
+        D.info = info.p; D.link = link.p; D.cr = cr.p; D.cg = cg.p; D.cb = cb.p; D.sr = sr.p; D.sg = sg.p; D.sb = sb.p;
         D.cap_tiles = (uint32_t)(arena_rays / TILE);
         D.lvl_shade_base = lvl_shade_base.p; D.list_ray = list_ray.p; D.list_node = list_node.p; D.redo_list = redo_list.p;
         for (int l = 0; l <= RT_MAX_LIGHTS; ++l) D.list_j[l] = list_j[l].n ? list_j[l].p : nullptr;
@@ -424,7 +424,7 @@ void rt_destroy(RtContext* ctx) {
     ctx->lvl_tilebase.release(); ctx->flags.release(); ctx->node_start.release(); ctx->node_pre.release();
     ctx->tile_run.release(); ctx->blk_tot.release(); ctx->wave_off.release();
     ctx->px.release(); ctx->py.release(); ctx->pz.release(); ctx->dx.release(); ctx->dy.release(); ctx->dz.release();
-    ctx->A.release(); ctx->dist.release(); ctx->cr.release(); ctx->cg.release(); ctx->cb.release();
+    ctx->A.release(); ctx->dist.release(); ctx->cr.release(); ctx->cg.release(); ctx->cb.release(); ctx->sr.release(); ctx->sg.release(); ctx->sb.release();
     ctx->info.release(); ctx->link.release(); ctx->list_ray.release(); ctx->redo_list.release(); ctx->list_node.release(); ctx->lvl_shade_base.release();
     for (auto& b : ctx->list_j) b.release();
     ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->packed32.release(); ctx->staging.release();
@@ -637,7 +637,7 @@ int rt_begin_frame(RtContext* ctx, int32_t row0, int32_t n_rows, const double* X
 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const size_t R = (size_t)arena_rays;
-    DevBuf<double>* dbl[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->dx, &ctx->dy, &ctx->dz, &ctx->A, &ctx->dist, &ctx->cr, &ctx->cg, &ctx->cb};
+    DevBuf<double>* dbl[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->dx, &ctx->dy, &ctx->dz, &ctx->A, &ctx->dist, &ctx->cr, &ctx->cg, &ctx->cb, &ctx->sr, &ctx->sg, &ctx->sb};
     for (auto* buf : dbl) HIP_TRY(buf->ensure(R));
     HIP_TRY(ctx->info.ensure(R));
     HIP_TRY(ctx->link.ensure(R));

@@ -50,8 +50,9 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
         for (int i = tid; i < D.S; i += BLOCK) s_cs[i] = sphere_consts(i);
     const V3 bg = ld3(D.sc->bg);
     const bool has_children = level + 1 < D.n_levels;
-    unsigned wave_base = 0;   // lane c < 3: children of kind c before this wave's first tile
-    if (lane < 3)
+    const int shade_base = D.lvl_shade_base[level];
+    unsigned wave_base = 0;   // lane c < 3: children of kind c before this wave's first tile; lane C_SHADE: shading-list entries
+    if (lane < 3 || lane == C_SHADE)
         wave_base = D.blk_tot[((size_t)level * NCNT + lane) * NB + blockIdx.x] + D.wave_off[((size_t)level * NCNT + lane) * NW + wid];
     __syncthreads();
 
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
             c.first = (t - __builtin_amdgcn_readfirstlane(r.tile0)) * TILE;
             const int cnt = min(TILE, __builtin_amdgcn_readfirstlane(r.n) - c.first);
             if (lane < cnt) c.info = D.info[(uint32_t)(tbase + t) * TILE + lane];
-            if (has_children && lane < 3) c.trun = D.tile_run[(size_t)(tbase + t) * NCNT + lane];
+            if ((has_children && lane < 3) || lane == C_SHADE) c.trun = D.tile_run[(size_t)(tbase + t) * NCNT + lane];
         }
         return c;
     };
@@ -117,9 +118,14 @@ __global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
                 for (int c = 0; c < 3; ++c)
                     slot[c] = T.child[cur[u].kn * 4 + c] + LANE(base, c) + lanes_below(__ballot(((in >> (18 + c)) & 1u) != 0));
             }
+            // the shading-list entry of a lit hit: the level's first entry + entries before this tile + lit hits in lower lanes
+            const unsigned long long lit = __ballot((in & I_SHADE) != 0);
+            uint32_t entry = 0;
+            if (lit != 0)
+                entry = (uint32_t)shade_base + LANE((int)(wave_base + cur[u].trun), C_SHADE) + lanes_below(lit);
             if ((in & I_LIVE) && is_hit(in)) {
                 A[u] = D.A[idx];
-                if (in & I_SHADE) surf[u] = {D.cr[idx], D.cg[idx], D.cb[idx]};
+                if (in & I_SHADE) surf[u] = {D.sr[entry], D.sg[entry], D.sb[entry]};
                 if (want_ti) {
                     const uint32_t sl = (in & I_CHILD_T) ? slot[C_T] : slot[C_I];
                     refr[u] = {D.cr[sl], D.cg[sl], D.cb[sl]};

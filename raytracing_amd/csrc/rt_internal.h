@@ -119,7 +119,9 @@ struct Dev {
     double *dist;           // path length inside the entered sphere (0: no attenuation)
     uint32_t* info;
     uint32_t* link;         // arena index of the parent ray
-    double *cr, *cg, *cb;   // surface colour (after k_surface), then ray colour (after k_combine)
+    double *cr, *cg, *cb;   // ray colour (after k_combine)
+    double *sr, *sg, *sb;   // surface colour of shading-list entry e (after the lighting kernels): dense, so that
+                            // the lighting kernels store and k_combine reads whole lines
     uint32_t cap_tiles;
     // dense list of the hits that need lighting, all levels one after the other
     int32_t* lvl_shade_base;   // [n_levels + 1] first list entry of each level; the last one is the total

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(BLOCK, LDS ? 2 : RT_SURFACE_WAVES_MANY) void k_surf
         const Surface sf = surface_at(P, centre, info & I_INSIDE, eps);
         V3 surf = surface_color<LDS>(D, sc, s_sh, lists, e, info, sf.Pb, d, sf.n, mat, my_samples);
         my_hits += 1;
-        D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
+        D.sr[e] = surf.x; D.sg[e] = surf.y; D.sb[e] = surf.z;
         e = e_next;
         ray = ray_next;
     }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
         unsigned a = 0;
         V3 surf = surface_color<LDS>(D, sc, s_sh, lists, e, info, sf.Pb, d, sf.n,
                                      surface_material(D.mat + (size_t)sid * RT_MAT_WIDTH), a);
-        D.cr[ray] = surf.x; D.cg[ray] = surf.y; D.cb[ray] = surf.z;
+        D.sr[e] = surf.x; D.sg[e] = surf.y; D.sb[e] = surf.z;
     }
 }
 
