@@ -333,7 +333,8 @@ def main():
     # ---- rooflines (rank 0's share of the work, its own kernel times) -------------------------
     # Algorithmic work per step from the device counters:
     #   k_trace   reads link (4 B) + parent info, hit point, direction (52 B) per non-primary ray,
-    #             writes info (4 B) per ray, 48 B per stored hit record, 16 B per live hit and the
+    #             writes info (4 B) per ray, 48 B per stored hit record, 8 B per live hit (its reflected fraction; the 8 B path
+    #             length that hits entering a transparent sphere store on top are not counted) and the
     #             per-tile counters (52 B per 64 rays);   FLOPs 22 per (ray, sphere) + 100 per hit
     #   k_surface reads 52 B per shaded hit and writes 24 B; per disk-light sample 8 B (the float32 pass
     #             reads the sample's point of the unit disk as two floats) or 16 B (float64 pass: two
@@ -343,7 +344,7 @@ def main():
     local = [job.local_stats() for job in jobs]
     sec = {k: v["ms"] * 1e-3 / args.steps for k, v in prof.items()}
     trace_bytes = sum(56 * (s["rays"] - s["pixels"]) + (4 + 52 / 64) * s["rays"] + 48 * s["stored_records"]
-                      + 16 * s["live_hits"] for s in local)
+                      + 8 * s["live_hits"] for s in local)
     trace_flops = sum(F_ISECT * s["rays"] * s["spheres"] + F_HIT * s["hits"] for s in local)
     mixed = all(job.precision == "mixed" for job in jobs)
     few_spheres = all(s["spheres"] <= 64 for s in local)      # the float32 sample pass and the LDS sphere loop apply

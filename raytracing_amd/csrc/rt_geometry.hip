@@ -458,7 +458,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
             }
             if (live) {
                 stream_store(A, &D.A[idx]);
-                stream_store(through, &D.dist[idx]);
+                if (b != 0 && trans && !inside) stream_store(through, &D.dist[idx]);   // k_combine reads it for these hits only
             }
         }
         if (valid) stream_store(info, &D.info[idx]);
