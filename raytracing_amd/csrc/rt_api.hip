@@ -97,26 +97,32 @@ int build_tree(int refl, int refr, HostTree& t) {
     return RT_OK;
 }
 
+__global__ __launch_bounds__(256) void k_fill_zero(uint32_t* p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool transient = false;   // a work buffer of one call: released again, no treatment on allocation
     hipError_t ensure(size_t count) {
         if (count <= n && p) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
         hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
-        // Measured on freshly started MI355X machines: kernels that stream through a large buffer in its
-        // first mapping run 4-5 % slower (19.3 vs 18.5 ms per 4K step) than through a buffer that was
-        // freed and allocated again, for as long as the buffer lives; later processes on the machine do
-        // not see it.  The cause is not established (the placement or page-table layout of first-use
-        // device memory), so a large buffer is simply allocated twice.  RT_ALLOC_TWICE=0 turns that off.
-        static const bool twice = !(getenv("RT_ALLOC_TWICE") && atoi(getenv("RT_ALLOC_TWICE")) == 0);
-        if (e == hipSuccess && twice && count * sizeof(T) >= (1u << 20)) {
-            (void)hipFree(p);
-            p = nullptr;
-            e = hipMalloc((void**)&p, count * sizeof(T));
+        // Measured on freshly started MI355X machines: kernels that stream through a large buffer run
+        // 4-5 % slower (19.3 vs 18.5 ms per 4K step) for as long as the buffer lives if parts of it have
+        // never been written (the arena is larger than what a frame fills, and hit records are stored
+        // for some lanes of a tile only) - a buffer that was written once from end to end, by this fill
+        // or, in memory a process had freed before, by the driver's clearing, does not show it.  So
+        // every large, lasting buffer is filled once when it is allocated.  RT_ALLOC_FILL=0 turns that off.
+        static const bool fill = !(getenv("RT_ALLOC_FILL") && atoi(getenv("RT_ALLOC_FILL")) == 0);
+        const size_t bytes = count * sizeof(T);
+        if (e == hipSuccess && fill && !transient && bytes >= (1u << 20)) {
+            hipLaunchKernelGGL(k_fill_zero, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(p), bytes / 4);
+            e = hipDeviceSynchronize();
         }
         if (e == hipSuccess) n = count;
         return e;
@@ -849,6 +855,7 @@ int rt_upload_samples_noalloc(RtContext* ctx, int64_t dst_offset, const double* 
     return RT_OK;
 }
 
+constexpr size_t MT_RAW_KEEP_BYTES = (size_t)64 << 30;
 int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32_t* key_out, int32_t* pos_out) {
     if (int rc = use_device(ctx)) return rc;
     if (!ctx->layout_set) return fail(RT_ERR_STATE, "rt_set_sample_layout has not been called");
@@ -877,11 +884,13 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     size_t free_bytes = 0, total_bytes = 0;
     HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
     long long budget = std::max<long long>(1ll << 28, (long long)(free_bytes / 2 / sizeof(uint32_t)));
+    budget = std::max(budget, (long long)ctx->mt_raw.n);   // what an earlier call kept is there already
     if (const char* e = getenv("RT_MT_RAW_WORDS")) budget = std::max(1ll, atoll(e));
     const int per_pass = (int)std::max<long long>(1, std::min<long long>(T, budget >> ell));
 
     HIP_TRY(ctx->mt_ring.ensure((size_t)T * MT_RING));
     HIP_TRY(ctx->mt_end.ensure((size_t)T));
+    ctx->mt_raw.transient = true;
     HIP_TRY(ctx->mt_raw.ensure((size_t)per_pass * L + 2));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::vector<uint32_t> ring(MT_RING, 0u);
@@ -938,7 +947,10 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         key_out[i] = (n > last_first ? ring : prev_ring)[n & (MT_RING - 1)];   // the last stream's own first word is not whole
     }
     *pos_out = (int32_t)(next - block * MT_N);
-    ctx->mt_raw.release();   // as large as the whole stream; only needed while it is being packed
+    // The raw words are only needed while they are being packed, but getting device memory back that
+    // some process has used before takes the driver tens of milliseconds per GB (measured: 1.3 s for
+    // the 50 GB of a 4K example_4 frame, every call), so a buffer of moderate size stays with the context.
+    if (ctx->mt_raw.n * sizeof(uint32_t) > MT_RAW_KEEP_BYTES) ctx->mt_raw.release();
     return RT_OK;
 }
 
