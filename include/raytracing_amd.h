@@ -257,7 +257,9 @@ int rt_upload_samples_noalloc(RtContext *ctx, int64_t dst_offset, const double *
  * there, the whole image's number of (in-beam) hits and the rank of this context's first hit
  * among them (rt_set_sample_layout_global, after rt_set_sample_layout; `total` = length of
  * the whole stream).  Every context then generates the whole stream and keeps its columns,
- * and all of them return the same final state. */
+ * and all of them return the same final state.  The generator's work buffer (8 bytes per value of
+ * the stream) stays with the context between calls while it is at most 64 GB; longer streams are
+ * made in several passes through a buffer that is released again. */
 int rt_set_sample_layout_global(RtContext *ctx, const int64_t *offsets, const int64_t *columns,
                                 const int64_t *first_column /* each [n_nodes][RT_MAX_LIGHTS] */, int64_t total);
 int rt_generate_samples(RtContext *ctx, const uint32_t *key /* [624] */, int32_t pos,
