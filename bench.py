@@ -441,7 +441,10 @@ def main():
                    "frames": args.frames,
                    "issue": ("frames one after the other, kernel by kernel" if serial else
                              ("HIP graph" if frames.graphs is not None else "kernel by kernel") +
-                             (", one all-reduce per bounce level, tiles travel during the next step" if frames.pipelined else "")),
+                             (", one all-reduce per bounce level, tiles travel during the next step" if frames.pipelined else "") +
+                             (f"; geometry speculated on the previous step's batch sizes with one all-reduce per step "
+                              f"({frames.speculation['steps']} steps, {frames.speculation['redone']} issued again level by level)"
+                              if frames.speculate else "")),
                    "precision": ("f64 everywhere except disk-light samples: f32 with certified "
                                  "shadow decisions, f64 re-evaluation of uncertified hits") if float32_samples else "f64 everywhere"},
         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},

@@ -220,6 +220,17 @@ int rt_set_batch_buffer(RtContext *ctx, int32_t *device_batches);
  * sizes of level l.  n_slots == 1 is rt_set_batch_buffer. */
 int rt_set_batch_buffer_shared(RtContext *ctx, int32_t *device_batches, int32_t slot, int32_t n_slots);
 
+/* Speculation for callers that re-render similar frames on several GPUs and want ONE sum of the
+ * batch sizes per frame instead of one per level: device_guess (same layout as the buffer of
+ * rt_set_batch_buffer / _shared, read only) holds what the caller expects the whole-image batch
+ * sizes to be, e.g. those of the previous frame, and the small-batch rule (reference
+ * raytrace.py:26-27) of the following geometry passes goes by it; the kernels still write this
+ * context's own sizes into the batch buffer.  After rt_trace_geometry the caller sums the buffer
+ * over its GPUs: if (guess < SMALL_NUM) == (sum < SMALL_NUM) for every node, the frame was traced
+ * exactly as with level-by-level sums; otherwise it has to be traced again (level by level, or
+ * with the sums as the new guess).  NULL switches the guess off.  No counterpart in the reference. */
+int rt_set_batch_guess(RtContext *ctx, const int32_t *device_guess);
+
 /* Per-node results of the geometry phase (synchronises):
  * batch[k] local rays of node k, hits[k] local hits, beam[k][l] local hits
  * inside spotlight l's beam.  Arrays may be NULL. */

@@ -90,6 +90,7 @@ SIGNATURES = {
     "rt_set_global_batches": (C.c_int, [_P, C.c_int32, _I64P]),
     "rt_set_batch_buffer": (C.c_int, [_P, _P]),
     "rt_set_batch_buffer_shared": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "rt_set_batch_guess": (C.c_int, [_P, _P]),
     "rt_get_node_counts": (C.c_int, [_P, _I64P, _I64P, _I64P]),
     "rt_set_sample_layout": (C.c_int, [_P, _I64P, C.c_int64]),
     "rt_upload_samples": (C.c_int, [_P, C.c_int64, _F64P, C.c_int64]),
@@ -327,6 +328,11 @@ class Context:
             _check(self.lib.rt_set_batch_buffer_shared(self._h, _P(device_ptr), int(slot), int(n_slots)))
         else:
             _check(self.lib.rt_set_batch_buffer(self._h, _P(device_ptr) if device_ptr else None))
+
+    def set_batch_guess(self, device_ptr):
+        """Sizes the small-batch rule goes by instead of the batch buffer's (same layout, read only;
+        see rt_set_batch_guess); None: off."""
+        _check(self.lib.rt_set_batch_guess(self._h, _P(device_ptr) if device_ptr else None))
 
     def node_counts(self):
         K = self.n_nodes

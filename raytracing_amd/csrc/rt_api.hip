@@ -188,6 +188,7 @@ struct RtContext {
     DevBuf<long long> mt_end;
     uint8_t* user_image8 = nullptr;
     int32_t* user_batches = nullptr;
+    const int32_t* batch_guess = nullptr;
     int batch_slot = 0, batch_slots = 1;
 
     // first element of a level's whole-image batch sizes (see whole_image_batch in rt_geometry.hip)
@@ -217,7 +218,7 @@ struct RtContext {
         D.hier_top = hier_top.p; D.hier_top_ref = hier_top_ref.p; D.hier_mid = hier_mid.p; D.hier_leaf = hier_leaf.p; D.hier_ids = hier_ids.p; D.hier_top_groups = hier_top_groups; D.hier_blocks = hier_blocks; D.hier_window = hier_window; D.hier_extent = hier_extent;
         D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
-        D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.batch_slot = batch_slot; D.batch_slots = batch_slots; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
+        D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.node_nguess = batch_guess; D.batch_slot = batch_slot; D.batch_slots = batch_slots; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
         D.node_tile0 = node_tile0.p; D.node_ntiles = node_ntiles.p; D.node_start = node_start.p; D.node_pre = node_pre.p;
         D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p; D.wave_off = wave_off.p;
         D.flags = flags.p; D.work = work.p;
@@ -615,6 +616,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
     ctx->spot_mask = spot_mask;
     for (auto& b : ctx->list_j) b.release();   // sized per frame for the lights of this scene
     ctx->user_batches = nullptr;
+    ctx->batch_guess = nullptr;
     ctx->batch_slot = 0; ctx->batch_slots = 1;
     ctx->have_scene = true;
     ctx->frame_begun = ctx->geometry_done = ctx->layout_set = ctx->shaded = false;
@@ -1021,6 +1023,13 @@ int rt_set_batch_buffer_shared(RtContext* ctx, int32_t* device_batches, int32_t 
         return fail(RT_ERR_INVALID, "slot %d of %d frames in a shared batch buffer", slot, n_slots);
     ctx->user_batches = device_batches;
     ctx->batch_slot = slot; ctx->batch_slots = n_slots;
+    return RT_OK;
+}
+
+int rt_set_batch_guess(RtContext* ctx, const int32_t* device_guess) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!ctx->have_scene) return fail(RT_ERR_STATE, "rt_set_scene has not been called");
+    ctx->batch_guess = device_guess;
     return RT_OK;
 }
 

@@ -14,6 +14,15 @@ __device__ __forceinline__ int32_t& whole_image_batch(const Dev& D, int k, int l
     return D.node_nglobal[k + (D.batch_slots - 1) * a + D.batch_slot * (b - a)];
 }
 
+// The size the small-batch rule (reference raytrace.py:26-27) compares with SMALL_NUM: the node's
+// whole-image batch size, or, while the caller has not summed the sizes over its GPUs yet, the
+// caller's guess for it (rt_set_batch_guess).
+__device__ __forceinline__ int32_t batch_for_small_rule(const Dev& D, int k, int level) {
+    if (!D.node_nguess) return whole_image_batch(D, k, level);
+    const int a = D.level_start[level], b = D.level_start[level + 1];
+    return D.node_nguess[k + (D.batch_slots - 1) * a + D.batch_slot * (b - a)];
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ void k_init(Dev D) {
     const int tid = threadIdx.x;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
             r.tile_end = t0 + D.node_ntiles[k];
             r.n = D.node_n[k];
             r.bits = (D.node_a[k] & 0xff) | ((D.node_b[k] & 0xff) << 8) | ((D.node_branch[k] & 0xff) << 16) |
-                     ((whole_image_batch(D, k, level) < small_num) ? (1 << 24) : 0);   // reference raytrace.py:26-27
+                     ((batch_for_small_rule(D, k, level) < small_num) ? (1 << 24) : 0);   // reference raytrace.py:26-27
             s_node[i] = r;
         }
         if (SMALL) {

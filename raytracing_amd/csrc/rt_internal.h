@@ -95,6 +95,7 @@ struct Dev {
     // per-frame node tables
     int32_t* node_n;        // local batch size
     int32_t* node_nglobal;  // whole-image batch sizes (== node_n on one GPU); use whole_image_batch()
+    const int32_t* node_nguess;  // null, or the sizes the small-batch rule goes by instead (same layout, not written)
     int32_t batch_slot;     // this frame's place and the number of frames when several frames share a
     int32_t batch_slots;    // caller's buffer level by level (0 and 1: the buffer holds this frame alone)
     int32_t* node_hits;

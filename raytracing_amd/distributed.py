@@ -615,6 +615,15 @@ class FrameSet:
     and a process group of their own while step k + 1 is computed; a buffer is reused only
     after its transfer has finished.
 
+    Steps after the first speculate (RT_SPECULATE=0: never): the whole-image batch sizes matter
+    only through the small-batch rule, i.e. through which nodes fall below SMALL_NUM, and for
+    frames that resemble the previous step's those are the same nodes.  The geometry of all levels
+    and frames is then ONE graph that goes by the previous step's sizes (rt_set_batch_guess), ONE
+    all-reduce sums the sizes it produced, and if every node lies on the same side of SMALL_NUM as
+    guessed, the step is exactly what the level-by-level exchange would have given.  Otherwise the
+    step is issued again level by level.  One collective and one host read per step instead of
+    one collective per level, and the frames are not joined after every level.
+
     RT_STEP_GRAPH=0 issues the same work without graphs.  With RT_BATCH_EXCHANGE=host the frames
     fall back to per-frame host-side exchanges, issued level by level."""
 
@@ -638,6 +647,7 @@ class FrameSet:
             K = build_tree(p.max_reflection_depth, p.max_refraction_depth).n_nodes
             with torch.cuda.stream(self.stream):
                 self.batches = torch.zeros(F * K, dtype=torch.int32, device=self.device)
+                self.guess_buffer = torch.zeros(F * K, dtype=torch.int32, device=self.device)
             self.stream.synchronize()
             shared = [(self.batches, f, F) for f in range(F)]
             self.comm.separate_tile_group()
@@ -648,6 +658,13 @@ class FrameSet:
         self.graphs = None
         self.steps_issued = 0
         self.tiles_sent = [None, None]        # event per output buffer: its last transfer has finished
+        self.speculate = self.pipelined and os.environ.get("RT_SPECULATE", "1") != "0"
+        self.guess = getattr(self, "guess_buffer", None) if self.speculate else None   # the last step's whole-image batch sizes
+        self.guess_valid = False
+        self.pending = None                   # (event, output buffer) of a speculative step whose outcome is not known yet
+        self.wrong_host = torch.zeros(1, dtype=torch.bool).pin_memory() if self.speculate else None
+        self.speculation = {"steps": 0, "redone": 0}
+        self.small_num = int(RenderParams(width=width, height=height).small_num)
 
     def prepare(self, seed=0):
         """Set every frame up (row split, first geometry pass, samples resident in HBM); every
@@ -703,6 +720,12 @@ class FrameSet:
         job.ctx.trace_geometry()
         job.ctx.shade()
 
+    def _geometry(self, job):
+        # the kernels of these launches (and of the graph captured from them) read the guess
+        job.ctx.set_batch_guess(self.guess.data_ptr())
+        job.ctx.trace_geometry()
+        job.ctx.set_batch_guess(None)
+
     def capture(self):
         try:
             if not self.sharded:
@@ -710,6 +733,8 @@ class FrameSet:
             else:
                 self.graphs = {"level": [self._captured(self._level(l)) for l in range(self.jobs[0].n_levels)],
                                "shade": [self._captured(self._shade(b)) for b in range(2)]}
+                if self.speculate:
+                    self.graphs["geometry"] = self._captured(self._geometry)
         except RuntimeError as exc:
             # the same work is then issued kernel by kernel (same order of collectives, so ranks
             # may differ in this); say so, the timing is affected
@@ -734,17 +759,45 @@ class FrameSet:
             for job in self.jobs:
                 job.step_finish()
             return
-        with torch.cuda.stream(self.stream):
-            if not self.sharded:
+        if not self.sharded:
+            with torch.cuda.stream(self.stream):
                 self._run("step", None, self._whole)
-                return
-            first = self.jobs[0].r
-            for level in range(first.tree.n_levels):
-                if level > 0:
-                    self.comm.all_reduce_device(first.level_batches(level, every_frame=True))
-                self._run("level", level, self._level(level))
-            b = self.steps_issued & 1
-            self.steps_issued += 1
+            return
+        self._settle()
+        b = self.steps_issued & 1
+        self.steps_issued += 1
+        with torch.cuda.stream(self.stream):
+            if self.speculate and self.guess_valid:
+                # all levels of all frames by the last step's sizes, one sum, and a look at the outcome
+                # that the host takes only when it comes back for the next step (_settle)
+                self._run("geometry", None, self._geometry)
+                self.comm.all_reduce_device(self.batches)
+                wrong = ((self.batches < self.small_num) != (self.guess < self.small_num)).any()
+                self.wrong_host.copy_(wrong, non_blocking=True)
+                looked = torch.cuda.Event()
+                looked.record(self.stream)
+                self.guess.copy_(self.batches)
+                self.pending = (looked, b)
+                self.speculation["steps"] += 1
+            else:
+                self._exact_levels()
+        self._finish(b)
+
+    def _exact_levels(self):
+        """Geometry of all frames level by level, one sum of the batch sizes per level (on the set's stream)."""
+        first = self.jobs[0].r
+        for level in range(first.tree.n_levels):
+            if level > 0:
+                self.comm.all_reduce_device(first.level_batches(level, every_frame=True))
+            self._run("level", level, self._level(level))
+        if self.speculate:
+            self.guess.copy_(self.batches)
+            self.guess_valid = True
+
+    def _finish(self, b):
+        """Lighting and colours into output buffer ``b``, then its tiles on their way to rank 0."""
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
             if self.tiles_sent[b] is not None:
                 self.stream.wait_event(self.tiles_sent[b])
             self._run("shade", b, self._shade(b))
@@ -759,7 +812,24 @@ class FrameSet:
         for job in self.jobs:                      # what image() reads and a later FrameJob.step() fills
             job.use_buffer(b)
 
+    def _settle(self):
+        """The outcome of the last speculative step: if some node fell on the other side of SMALL_NUM
+        than guessed, that step is issued again level by level, into the same output buffer (every
+        rank sees the same sums, so every rank does)."""
+        if self.pending is None:
+            return
+        looked, b = self.pending
+        self.pending = None
+        looked.synchronize()
+        if bool(self.wrong_host.item()):
+            self.speculation["redone"] += 1
+            with self.torch.cuda.stream(self.stream):
+                self._exact_levels()
+            self._finish(b)
+
     def synchronize(self):
+        if self.sharded and self.pipelined:
+            self._settle()
         for job in self.jobs:
             job.synchronize()
         self.stream.synchronize()

@@ -137,6 +137,19 @@ def _worker_frame_set(rank, world, port, w, h, out_path, env):
         frames.step()                           # two steps in flight without a host synchronisation between
         frames.step()
         per_step.append(frames.images())
+        if frames.speculate:
+            # the steps after the first went by the previous step's batch sizes and were confirmed
+            assert frames.speculation == {"steps": 4, "redone": 0}, frames.speculation
+            # a guess that puts nodes on the wrong side of SMALL_NUM is noticed and the step issued again
+            frames.guess.zero_()
+            frames.step()
+            per_step.append(frames.images())
+            assert frames.speculation == {"steps": 5, "redone": 1}, frames.speculation
+            frames.step()
+            per_step.append(frames.images())
+            assert frames.speculation == {"steps": 6, "redone": 1}, frames.speculation
+        else:
+            assert frames.speculation["steps"] == 0
         stats = [job.stats() for job in frames.jobs]
         if rank == 0:
             np.savez(out_path, images=np.array(per_step), rays=[s["rays"] for s in stats],
@@ -146,18 +159,19 @@ def _worker_frame_set(rank, world, port, w, h, out_path, env):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("env", [{}, {"RT_STEP_GRAPH": "0"}, {"RT_BATCH_EXCHANGE": "host"}],
-                         ids=["graphs", "no-graphs", "host-exchange"])
+@pytest.mark.parametrize("env", [{}, {"RT_STEP_GRAPH": "0"}, {"RT_BATCH_EXCHANGE": "host"}, {"RT_SPECULATE": "0"}],
+                         ids=["graphs", "no-graphs", "host-exchange", "no-speculation"])
 def test_frame_set_two_ranks_on_one_gpu(tmp_path, env):
     g = np.load(os.path.join(GOLDEN, "images_160x90.npz"))
     out = str(tmp_path / "set.npz")
     mp.spawn(_worker_frame_set, args=(2, _free_port(), 160, 90, out, env), nprocs=2, join=True)
     res = np.load(out)
-    assert res["images"].shape == (4, len(SET_SCENES), 90, 160, 3)
+    n_sets = res["images"].shape[0]
+    assert res["images"].shape == (n_sets, len(SET_SCENES), 90, 160, 3) and n_sets in (4, 6)
     for f, name in enumerate(SET_SCENES):
         tol = 2e-5 if name == "example_4" else 1e-8
         assert 0 < res["bounds"][f][1] < 90
-        for step in range(4):
+        for step in range(n_sets):
             assert np.abs(res["images"][step, f] - g[name + "_image"]).max() <= tol, (name, step)
             assert np.array_equal(res["images"][step, f], res["images"][0, f])
         r = g[name + "_rays"]
@@ -242,7 +256,7 @@ def _worker_one_rank_rccl(rank, world, port, w, h, out_path):
         from raytracing_amd.distributed import FrameSet
         frames = FrameSet(SET_SCENES, w, h, device=0, rank=rank, world=world, group=dist.group.WORLD)
         frames.prepare(seed=0)
-        assert frames.sharded and frames.pipelined and frames.graphs is not None
+        assert frames.sharded and frames.pipelined and frames.graphs is not None and frames.speculate
         per_step = []
         for _ in range(3):
             frames.step()
@@ -250,6 +264,7 @@ def _worker_one_rank_rccl(rank, world, port, w, h, out_path):
         frames.step()
         frames.step()
         per_step.append(frames.images())
+        assert frames.speculation == {"steps": 4, "redone": 0}, frames.speculation
         np.savez(out_path, images=np.array(per_step))
         frames.close()
     finally:
