@@ -617,12 +617,12 @@ class FrameSet:
 
     Steps after the first speculate (RT_SPECULATE=0: never): the whole-image batch sizes matter
     only through the small-batch rule, i.e. through which nodes fall below SMALL_NUM, and for
-    frames that resemble the previous step's those are the same nodes.  The geometry of all levels
-    and frames is then ONE graph that goes by the previous step's sizes (rt_set_batch_guess), ONE
-    all-reduce sums the sizes it produced, and if every node lies on the same side of SMALL_NUM as
-    guessed, the step is exactly what the level-by-level exchange would have given.  Otherwise the
-    step is issued again level by level.  One collective and one host read per step instead of
-    one collective per level, and the frames are not joined after every level.
+    frames that resemble the previous step's those are the same nodes.  The whole step (all levels
+    and the lighting of all frames) is then ONE graph that goes by the previous step's sizes
+    (rt_set_batch_guess), ONE all-reduce behind it sums the sizes it produced, and if every node
+    lies on the same side of SMALL_NUM as guessed, the step is exactly what the level-by-level
+    exchange would have given.  The host learns the outcome when it comes back for the next step
+    (or synchronises); a step whose guess was wrong is then issued again level by level.
 
     RT_STEP_GRAPH=0 issues the same work without graphs.  With RT_BATCH_EXCHANGE=host the frames
     fall back to per-frame host-side exchanges, issued level by level."""
@@ -720,11 +720,15 @@ class FrameSet:
         job.ctx.trace_geometry()
         job.ctx.shade()
 
-    def _geometry(self, job):
-        # the kernels of these launches (and of the graph captured from them) read the guess
-        job.ctx.set_batch_guess(self.guess.data_ptr())
-        job.ctx.trace_geometry()
-        job.ctx.set_batch_guess(None)
+    def _speculative(self, buffer):
+        def body(job):
+            # the kernels of these launches (and of the graph captured from them) read the guess
+            job.ctx.set_batch_guess(self.guess.data_ptr())
+            job.use_buffer(buffer)
+            job.ctx.trace_geometry()
+            job.ctx.shade()
+            job.ctx.set_batch_guess(None)
+        return body
 
     def capture(self):
         try:
@@ -734,7 +738,7 @@ class FrameSet:
                 self.graphs = {"level": [self._captured(self._level(l)) for l in range(self.jobs[0].n_levels)],
                                "shade": [self._captured(self._shade(b)) for b in range(2)]}
                 if self.speculate:
-                    self.graphs["geometry"] = self._captured(self._geometry)
+                    self.graphs["speculative"] = [self._captured(self._speculative(b)) for b in range(2)]
         except RuntimeError as exc:
             # the same work is then issued kernel by kernel (same order of collectives, so ranks
             # may differ in this); say so, the timing is affected
@@ -766,11 +770,17 @@ class FrameSet:
         self._settle()
         b = self.steps_issued & 1
         self.steps_issued += 1
-        with torch.cuda.stream(self.stream):
-            if self.speculate and self.guess_valid:
-                # all levels of all frames by the last step's sizes, one sum, and a look at the outcome
-                # that the host takes only when it comes back for the next step (_settle)
-                self._run("geometry", None, self._geometry)
+        if self.speculate and self.guess_valid:
+            # Geometry of all levels by the last step's sizes and the lighting right behind it, every
+            # frame on its own stream as on one GPU; then one sum of the batch sizes and a look at
+            # the outcome, which the host takes only when it comes back for the next step (_settle).
+            # Nothing on the device waits for the collective.
+            with torch.cuda.stream(self.stream):
+                if self.tiles_sent[b] is not None:
+                    self.stream.wait_event(self.tiles_sent[b])
+                self._run("speculative", b, self._speculative(b))
+                shaded = torch.cuda.Event()
+                shaded.record(self.stream)
                 self.comm.all_reduce_device(self.batches)
                 wrong = ((self.batches < self.small_num) != (self.guess < self.small_num)).any()
                 self.wrong_host.copy_(wrong, non_blocking=True)
@@ -779,9 +789,11 @@ class FrameSet:
                 self.guess.copy_(self.batches)
                 self.pending = (looked, b)
                 self.speculation["steps"] += 1
-            else:
+            self._send(b, shaded)
+        else:
+            with torch.cuda.stream(self.stream):
                 self._exact_levels()
-        self._finish(b)
+            self._finish(b)
 
     def _exact_levels(self):
         """Geometry of all frames level by level, one sum of the batch sizes per level (on the set's stream)."""
@@ -803,6 +815,11 @@ class FrameSet:
             self._run("shade", b, self._shade(b))
             shaded = torch.cuda.Event()
             shaded.record(self.stream)
+        self._send(b, shaded)
+
+    def _send(self, b, shaded):
+        """The tiles of output buffer ``b`` travel to rank 0 on the tile stream once ``shaded`` has happened."""
+        torch = self.torch
         with torch.cuda.stream(self.tile_stream):
             self.tile_stream.wait_event(shaded)
             self.comm.gather_tiles_many([(j.fulls[b], j.tiles[b], j.r.bounds, j.width) for j in self.jobs])
