@@ -111,16 +111,26 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
-        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
-        // Measured on freshly started MI355X machines: kernels that stream through a large buffer run
-        // 4-5 % slower (19.3 vs 18.5 ms per 4K step) for as long as the buffer lives if parts of it have
-        // never been written (the arena is larger than what a frame fills, and hit records are stored
-        // for some lanes of a tile only) - a buffer that was written once from end to end, by this fill
-        // or, in memory a process had freed before, by the driver's clearing, does not show it.  So
-        // every large, lasting buffer is filled once when it is allocated.  RT_ALLOC_FILL=0 turns that off.
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        hipError_t e = hipMalloc((void**)&p, bytes);
+        // Measured on freshly started MI355X machines: kernels that stream through large buffers in
+        // their first mapping run 4-5 % slower (19.3 vs 18.5 ms per 4K step) for as long as the buffers
+        // live; processes that come later on the machine hardly show it.  Two things bring the first
+        // process level with the later ones, each about half of the way (18.6 with either, 17.9-18.0
+        // with both): writing every large, lasting buffer once from end to end (the arena is larger
+        // than what a frame fills, and hit records are stored for some lanes of a tile only, so parts
+        // of a buffer are otherwise never written), and giving a buffer back at once and asking for it
+        // again.  The cause is not established.  The price is set-up time where the driver has to
+        // clear memory that was used before (25-40 GB/s: seconds for a set of 4K frames in a process
+        // that is not the machine's first).  RT_ALLOC_FILL=0 turns both off.
         static const bool fill = !(getenv("RT_ALLOC_FILL") && atoi(getenv("RT_ALLOC_FILL")) == 0);
-        const size_t bytes = count * sizeof(T);
-        if (e == hipSuccess && fill && !transient && bytes >= (1u << 20)) {
+        const bool lasting = fill && !transient && bytes >= (1u << 20);
+        if (e == hipSuccess && lasting && bytes >= ((size_t)64 << 20)) {
+            (void)hipFree(p);
+            p = nullptr;
+            e = hipMalloc((void**)&p, bytes);
+        }
+        if (e == hipSuccess && lasting) {
             hipLaunchKernelGGL(k_fill_zero, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(p), bytes / 4);
             e = hipDeviceSynchronize();
         }
