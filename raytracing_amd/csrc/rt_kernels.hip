@@ -30,6 +30,9 @@
 #ifndef RT_TRACE_WAVES_MANY
 #define RT_TRACE_WAVES_MANY 4   // the same for the many-sphere variant of k_trace
 #endif
+#ifndef RT_SURFACE_WAVES
+#define RT_SURFACE_WAVES 2   // waves per SIMD requested for the float64 lighting kernel (few spheres)
+#endif
 #ifndef RT_SURFACE_WAVES_MANY
 #define RT_SURFACE_WAVES_MANY 4   // waves per SIMD requested for the many-sphere variant of k_surface (measured: 2: 42.9 ms, 4: 40.2, 6: 44.3 for 4096 spheres at 4K)
 #endif

@@ -257,7 +257,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
 // ---------------------------------------------------------------------------------------------
 // Lighting in float64 for the dense list of hits whose surface colour matters (all levels).
 template <bool LDS>
-__global__ __launch_bounds__(BLOCK, LDS ? 2 : RT_SURFACE_WAVES_MANY) void k_surface(Dev D) {
+__global__ __launch_bounds__(BLOCK, LDS ? RT_SURFACE_WAVES : RT_SURFACE_WAVES_MANY) void k_surface(Dev D) {
     constexpr int TABLE = LDS ? SHADE_LDS_SPHERES : 1;
     __shared__ ShadowSphere s_sh[TABLE];
     __shared__ SurfaceMaterial s_mat[TABLE];
