@@ -698,7 +698,7 @@ __device__ __forceinline__ LevelTables stage_level_tables(const Dev& D, int leve
 static_assert(NCNT <= 16, "counter tables in LDS have 16 columns");
 // Ordered compaction: every child slot of the next level learns its parent, and the
 // hits that need lighting are appended to the dense shading list.
-__global__ __launch_bounds__(BLOCK) void k_link(Dev D, int level) {
+__global__ __launch_bounds__(BLOCK, RT_LINK_WAVES) void k_link(Dev D, int level) {
     extern __shared__ int s_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (D.flags[0]) return;  // arena overflow: child slots do not exist

@@ -28,7 +28,7 @@ struct CombineTile {   // first stage of the pipeline: what is known / requested
     unsigned trun;     // lanes 0-2: running child counts at the tile's start
 };
 template <bool SMALL>   // SMALL: at most SPH_CHUNK_SMALL spheres, their constants in LDS
-__global__ __launch_bounds__(BLOCK) void k_combine(Dev D, int level) {
+__global__ __launch_bounds__(BLOCK, RT_COMBINE_WAVES) void k_combine(Dev D, int level) {
     extern __shared__ int s_dyn[];
     __shared__ CombineSphere s_cs[SMALL ? SPH_CHUNK_SMALL : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -30,6 +30,12 @@
 #ifndef RT_TRACE_WAVES_MANY
 #define RT_TRACE_WAVES_MANY 4   // the same for the many-sphere variant of k_trace
 #endif
+#ifndef RT_COMBINE_WAVES
+#define RT_COMBINE_WAVES 4   // waves per SIMD requested for k_combine (measured: 4: 3.25 ms per step, 5: 4.8, 6: 6.6)
+#endif
+#ifndef RT_LINK_WAVES
+#define RT_LINK_WAVES 8      // ... and k_link (6: 2.18 ms, 8: 2.06)
+#endif
 #ifndef RT_SURFACE_WAVES
 #define RT_SURFACE_WAVES 2   // waves per SIMD requested for the float64 lighting kernel (few spheres)
 #endif
