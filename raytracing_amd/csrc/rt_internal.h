@@ -10,7 +10,10 @@ namespace rt {
 constexpr int TILE = 64;              // rays per tile = one wavefront
 constexpr int BLOCK = 256;            // threads per workgroup
 constexpr int WPB = BLOCK / TILE;     // waves per workgroup
-constexpr int NB = 2048;              // workgroups per level launch (256 CUs x 8)
+#ifndef RT_NB
+#define RT_NB 2048
+#endif
+constexpr int NB = RT_NB;              // workgroups per level launch (256 CUs x 8)
 constexpr int NW = NB * WPB;          // waves per level launch; each owns a contiguous run of tiles
 constexpr int NCNT = RT_NUM_COUNTERS; // per-tile counters: 3 child kinds, hits, in-beam per light, shade items
 constexpr int MAX_LEVELS = 32;
