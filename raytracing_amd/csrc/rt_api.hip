@@ -211,6 +211,7 @@ struct RtContext {
     int row0 = 0;
     bool explicit_xy = false;
     int64_t arena_rays = 0;
+    int nb = NB;   // workgroups per level launch of the current frame (see rt_begin_frame)
     int64_t sample_total = 0;
     int64_t samples_delivered = 0;   // values uploaded or generated since the layout was set
     double* upload_scratch = nullptr;   // this GPU's g_upload_scratch (see upload_scratch_of)
@@ -228,7 +229,7 @@ struct RtContext {
         D.hier_top = hier_top.p; D.hier_top_ref = hier_top_ref.p; D.hier_mid = hier_mid.p; D.hier_leaf = hier_leaf.p; D.hier_ids = hier_ids.p; D.hier_top_groups = hier_top_groups; D.hier_blocks = hier_blocks; D.hier_window = hier_window; D.hier_extent = hier_extent;
         D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
-        D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.node_nguess = batch_guess; D.batch_slot = batch_slot; D.batch_slots = batch_slots; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
+        D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.nb = nb; D.node_nguess = batch_guess; D.batch_slot = batch_slot; D.batch_slots = batch_slots; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
         D.node_tile0 = node_tile0.p; D.node_ntiles = node_ntiles.p; D.node_start = node_start.p; D.node_pre = node_pre.p;
         D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p; D.wave_off = wave_off.p;
         D.flags = flags.p; D.work = work.p;
@@ -305,14 +306,14 @@ hipError_t raise_dynamic_lds_limit() {
 int launch_level(RtContext* ctx, int level) {
     const Dev D = ctx->dev();
     ctx->begin(RT_K_TRACE);
-    if (ctx->S <= SPH_CHUNK_SMALL) hipLaunchKernelGGL((k_trace<true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
-    else hipLaunchKernelGGL((k_trace<false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D, level);
+    if (ctx->S <= SPH_CHUNK_SMALL) hipLaunchKernelGGL((k_trace<true>), dim3(ctx->nb), dim3(BLOCK), 0, ctx->stream, D, level);
+    else hipLaunchKernelGGL((k_trace<false>), dim3(ctx->nb), dim3(BLOCK), 0, ctx->stream, D, level);
     ctx->end();
     ctx->begin(RT_K_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, D, level);
     ctx->end();
     ctx->begin(RT_K_LINK);
-    hipLaunchKernelGGL(k_link, dim3(NB), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
+    hipLaunchKernelGGL(k_link, dim3(ctx->nb), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
     ctx->end();
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -676,6 +677,12 @@ int rt_begin_frame(RtContext* ctx, int32_t row0, int32_t n_rows, const double* X
     }
     ctx->user_image = nullptr;
     ctx->user_image8 = nullptr;
+    // Workgroups per level launch: half as many for frames of up to three megapixels (measured: 1080p
+    // frames 5.18 -> 5.00 ms, a 3840x540 strip 5.60 -> 5.39 ms with 1024 workgroups - k_scan walks fewer
+    // totals, fewer workgroups find nothing to do; 4K frames lose with 1024: k_link 2.04 -> 2.40 ms).
+    // RT_LEVEL_WORKGROUPS overrides (a multiple of 256).
+    ctx->nb = npix <= 3000000 ? std::min(NB, 1024) : NB;
+    if (const char* e = getenv("RT_LEVEL_WORKGROUPS")) ctx->nb = std::max(256, std::min(NB, atoi(e) / 256 * 256));
     ctx->npix = npix;
     ctx->row0 = X ? 0 : row0;
     ctx->arena_rays = arena_rays;
@@ -1008,9 +1015,9 @@ int rt_shade(RtContext* ctx) {
     for (int level = D.n_levels - 1; level >= 0; --level) {
         ctx->begin(RT_K_COMBINE);
         if (ctx->S <= SPH_CHUNK_SMALL)
-            hipLaunchKernelGGL((k_combine<true>), dim3(NB), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
+            hipLaunchKernelGGL((k_combine<true>), dim3(ctx->nb), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
         else
-            hipLaunchKernelGGL((k_combine<false>), dim3(NB), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
+            hipLaunchKernelGGL((k_combine<false>), dim3(ctx->nb), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
         ctx->end();
     }
     HIP_TRY(hipGetLastError());

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = tiles_per_wave(nt);
+    const int q = tiles_per_wave(D, nt);
     const int wid = blockIdx.x * WPB + wave;
     const int t_first = wid * q;
     const int S = D.S;
@@ -533,19 +533,21 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = tiles_per_wave(nt);
+    const int q = tiles_per_wave(D, nt);
 
     // 1. exclusive scan of the per-workgroup totals (stored counter-major), one wave per
     //    counter; every lane owns a run of consecutive entries and has all its loads in flight
     if (wave < NCNT) {
-        constexpr int PER = NB / 64;
-        uint32_t* base = D.blk_tot + ((size_t)level * NCNT + wave) * NB + lane * PER;
-        uint4 v[PER / 4];
+        // (D.nb workgroups ran, a multiple of 256: every lane owns D.nb / 64 entries, four to a load)
+        constexpr int MAX_LOADS = NB / 64 / 4;
+        const int per = D.nb / 64, loads = per / 4;
+        uint32_t* base = D.blk_tot + ((size_t)level * NCNT + wave) * NB + lane * per;
+        uint4 v[MAX_LOADS];
         unsigned sum = 0;
 #pragma unroll
-        for (int i = 0; i < PER / 4; ++i) v[i] = reinterpret_cast<const uint4*>(base)[i];
+        for (int i = 0; i < MAX_LOADS; ++i) v[i] = i < loads ? reinterpret_cast<const uint4*>(base)[i] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < PER / 4; ++i) sum += v[i].x + v[i].y + v[i].z + v[i].w;
+        for (int i = 0; i < MAX_LOADS; ++i) sum += v[i].x + v[i].y + v[i].z + v[i].w;
         unsigned incl = sum;
         for (int off = 1; off < 64; off <<= 1) {
             unsigned up = __shfl_up(incl, off);
@@ -553,13 +555,13 @@ __global__ __launch_bounds__(1024) void k_scan(Dev D, int level) {
         }
         unsigned running = incl - sum;
 #pragma unroll
-        for (int i = 0; i < PER / 4; ++i) {
+        for (int i = 0; i < MAX_LOADS; ++i) {
             uint4 o;
             o.x = running; running += v[i].x;
             o.y = running; running += v[i].y;
             o.z = running; running += v[i].z;
             o.w = running; running += v[i].w;
-            reinterpret_cast<uint4*>(base)[i] = o;
+            if (i < loads) reinterpret_cast<uint4*>(base)[i] = o;
         }
         if (lane == 63) s_grand[wave] = incl;
     }
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(BLOCK, RT_LINK_WAVES) void k_link(Dev D, int level)
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = tiles_per_wave(nt);
+    const int q = tiles_per_wave(D, nt);
     const int wid = blockIdx.x * WPB + wave;
     const int t_begin = wid * q;
     const int t_end = min(nt, t_begin + q);

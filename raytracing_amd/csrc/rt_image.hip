@@ -36,7 +36,7 @@ __global__ __launch_bounds__(BLOCK, RT_COMBINE_WAVES) void k_combine(Dev D, int 
     const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
     const int nt = D.lvl_ntiles[level];
     const int tbase = D.lvl_tilebase[level];
-    const int q = tiles_per_wave(nt);
+    const int q = tiles_per_wave(D, nt);
     const int wid = blockIdx.x * WPB + wave;
     const int t_begin = wid * q;
     const int t_end = min(nt, t_begin + q);

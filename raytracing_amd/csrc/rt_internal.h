@@ -110,6 +110,7 @@ struct Dev {
     int32_t* lvl_ntiles;    // [n_levels]
     int32_t* lvl_tilebase;  // [n_levels] first tile of the level in the arena
     uint32_t* tile_run;     // [tiles][NCNT] running counter value inside the producing wave
+    int nb;                 // workgroups of this frame's level launches (a multiple of 256, at most NB)
     uint32_t* blk_tot;      // [n_levels][NCNT][NB] per-workgroup totals, turned into prefixes by k_scan
     uint32_t* wave_off;     // [n_levels][NCNT][NW] counter value at a wave's first tile relative to its workgroup
     int32_t* flags;         // [0] overflow, [1] entries queued for float64 re-evaluation

@@ -127,7 +127,11 @@ __device__ __forceinline__ v2f cull_test(const CullPair& p, float ox, float oy, 
 #ifndef RT_MIN_TILES_PER_WAVE
 #define RT_MIN_TILES_PER_WAVE 8
 #endif
-__device__ __forceinline__ int tiles_per_wave(int nt) { return max((nt + NW - 1) / NW, RT_MIN_TILES_PER_WAVE); }
+// (the level kernels of a frame run with D.nb workgroups: fewer for small frames, see rt_begin_frame)
+__device__ __forceinline__ int tiles_per_wave(const Dev& D, int nt) {
+    const int waves = D.nb * WPB;
+    return max((nt + waves - 1) / waves, RT_MIN_TILES_PER_WAVE);
+}
 
 constexpr int CAND_MAX = 16;   // survivors a lane collects before the wave tests them
 // Number of set bits of a wave ballot below the calling lane.
