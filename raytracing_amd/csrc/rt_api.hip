@@ -677,11 +677,11 @@ int rt_begin_frame(RtContext* ctx, int32_t row0, int32_t n_rows, const double* X
     }
     ctx->user_image = nullptr;
     ctx->user_image8 = nullptr;
-    // Workgroups per level launch: half as many for frames of up to three megapixels (measured: 1080p
+    // Workgroups per level launch: half as many for frames of up to five megapixels (measured: 1080p
     // frames 5.18 -> 5.00 ms, a 3840x540 strip 5.60 -> 5.39 ms with 1024 workgroups - k_scan walks fewer
-    // totals, fewer workgroups find nothing to do; 4K frames lose with 1024: k_link 2.04 -> 2.40 ms).
+    // totals, fewer workgroups find nothing to do; 4K frames are level: k_link 2.04 -> 2.40 ms, k_scan 0.69 -> 0.46).
     // RT_LEVEL_WORKGROUPS overrides (a multiple of 256).
-    ctx->nb = npix <= 3000000 ? std::min(NB, 1024) : NB;
+    ctx->nb = npix <= 5000000 ? std::min(NB, 1024) : NB;
     if (const char* e = getenv("RT_LEVEL_WORKGROUPS")) ctx->nb = std::max(256, std::min(NB, atoi(e) / 256 * 256));
     ctx->npix = npix;
     ctx->row0 = X ? 0 : row0;
