@@ -246,14 +246,17 @@ int rt_get_node_counts(RtContext *ctx, int64_t *batch, int64_t *hits, int64_t *b
 int rt_set_sample_layout(RtContext *ctx, const int64_t *offsets /* [n_nodes][RT_MAX_LIGHTS] */, int64_t total);
 int rt_upload_samples(RtContext *ctx, int64_t dst_offset, const double *u, int64_t n);
 
-/* rt_upload_samples for callers that must not allocate device memory (code running under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
- * reference.  Same arguments, meaning and result as rt_upload_samples, but the piece of the
- * stream is staged in an array that is part of the library's code object (one per GPU, 8 MiB,
- * held until the process ends) instead of a buffer that grows on demand: the call makes no
- * hipMalloc / hipFree.  n must not exceed RT_NOALLOC_MAX_SAMPLES; longer streams are uploaded in
- * several calls.  All contexts on one GPU share the array: calls on the same GPU must not
- * overlap in time (each call waits for its own scatter before it returns). */
+/* rt_upload_samples for callers that must not allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, processes whose memory pool is fixed at start-up).  No
+ * counterpart in the reference.  Same arguments, meaning and result as rt_upload_samples, but the
+ * piece of the stream is staged in an array that is part of the library's code object (one per
+ * GPU, 8 MiB, held until the process ends) instead of a buffer that grows on demand: the call
+ * makes no hipMalloc / hipFree.  Like rt_upload_samples it waits for the context's stream before
+ * it overwrites the array and again before it returns (u is ordinary host memory and may be reused
+ * at once), so it cannot be recorded into a HIP graph: a stream capture that is active on the
+ * context's stream is invalidated by it.  n must not exceed RT_NOALLOC_MAX_SAMPLES; longer streams
+ * are uploaded in several calls.  All contexts on one GPU share the array: calls on the same GPU
+ * must not overlap in time. */
 #define RT_NOALLOC_MAX_SAMPLES (1 << 20)
 int rt_upload_samples_noalloc(RtContext *ctx, int64_t dst_offset, const double *u, int64_t n);
 

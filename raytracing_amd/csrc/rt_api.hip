@@ -10,11 +10,16 @@
 #include <string>
 #include <vector>
 
+#include "host_tree.h"
 #include "mt_jump.h"
 #include "rt_kernels.hip"
 #include "hier_build.h"
 
 using namespace rt;
+
+#ifndef RT_ALLOC_FILL_DEFAULT
+#define RT_ALLOC_FILL_DEFAULT 1   // see alloc_treatment()
+#endif
 
 // Staging memory of rt_upload_samples_noalloc: one array per GPU, part of the loaded code object,
 // so using it needs no allocation.  Host code must not use the array's name as an address (it is a
@@ -61,44 +66,40 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-struct HostTree {
-    std::vector<int32_t> a, b, parent, branch, child, level, level_start;
-    int n_nodes() const { return (int)a.size(); }
-    int n_levels() const { return (int)level_start.size() - 1; }
-};
-
-// Breadth-first enumeration of the recursion pattern of reference raytrace.py:103-133.
+// Breadth-first enumeration of the recursion pattern of reference raytrace.py:103-133 (host_tree.h).
+static_assert(HOST_TREE_MAX_NODES == MAX_NODES, "the host tree and the device tables agree on the node limit");
 int build_tree(int refl, int refr, HostTree& t) {
-    if (refl < 0 || refr < 0) return fail(RT_ERR_INVALID, "depth limits must be non-negative");
-    t = HostTree();
-    t.a.push_back(refl); t.b.push_back(refr); t.parent.push_back(-1); t.branch.push_back(-1);
-    t.level.push_back(0); t.child.insert(t.child.end(), {-1, -1, -1});
-    t.level_start.push_back(0);
-    size_t begin = 0, end = 1;
-    while (begin < end) {
-        t.level_start.push_back((int32_t)end);
-        for (size_t node = begin; node < end; ++node) {
-            const int na = t.a[node], nb = t.b[node];
-            const bool allowed[3] = {nb != 0, na != 0 && nb != 0, na != 0};
-            const int ca[3] = {na, na - 1, na - 1}, cb[3] = {nb - 1, nb - 1, nb};
-            for (int c = 0; c < 3; ++c) {
-                if (!allowed[c]) continue;
-                if (t.a.size() >= (size_t)MAX_NODES)
-                    return fail(RT_ERR_INVALID, "ray tree for depths (%d, %d) has more than %d nodes", refl, refr, MAX_NODES);
-                t.child[node * 3 + c] = (int32_t)t.a.size();
-                t.a.push_back(ca[c]); t.b.push_back(cb[c]); t.parent.push_back((int32_t)node);
-                t.branch.push_back(c); t.level.push_back(t.level[node] + 1);
-                t.child.insert(t.child.end(), {-1, -1, -1});
-            }
-        }
-        begin = end;
-        end = t.a.size();
-    }
+    const std::string problem = build_host_tree(refl, refr, t);
+    if (!problem.empty()) return fail(RT_ERR_INVALID, "%s", problem.c_str());
     return RT_OK;
 }
 
-__global__ __launch_bounds__(256) void k_fill_zero(uint32_t* p, size_t words) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+// Writes a buffer once from end to end: zeros, or (garbage != 0, an experiment's control) a word
+// pattern with about half of its bits set.
+__global__ __launch_bounds__(256) void k_fill(uint32_t* p, size_t words, uint32_t garbage) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) {
+        uint32_t v = 0u;
+        if (garbage) {
+            v = (uint32_t)i * 2654435761u + garbage;
+            v ^= v >> 15; v *= 2246822519u; v ^= v >> 13;
+        }
+        p[i] = v;
+    }
+}
+
+// Stream of the context whose call is allocating on this thread (set by use_device): the first
+// write of a new buffer is queued there.
+thread_local hipStream_t g_alloc_stream = nullptr;
+
+// What DevBuf::ensure does with a large, lasting buffer after hipMalloc (RT_ALLOC_FILL):
+// bit 0: write it once from end to end (zeros); bit 1: give it back and ask again first;
+// 4: write a word pattern instead of zeros (control of the measurement described in ensure()).
+int alloc_treatment() {
+    static const int mode = [] {
+        const char* e = getenv("RT_ALLOC_FILL");
+        return e ? atoi(e) : RT_ALLOC_FILL_DEFAULT;
+    }();
+    return mode;
 }
 
 template <typename T>
@@ -113,26 +114,28 @@ struct DevBuf {
         n = 0;
         const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
         hipError_t e = hipMalloc((void**)&p, bytes);
-        // Measured on freshly started MI355X machines: kernels that stream through large buffers in
-        // their first mapping run 4-5 % slower (19.3 vs 18.5 ms per 4K step) for as long as the buffers
-        // live; processes that come later on the machine hardly show it.  Two things bring the first
-        // process level with the later ones, each about half of the way (18.6 with either, 17.9-18.0
-        // with both): writing every large, lasting buffer once from end to end (the arena is larger
-        // than what a frame fills, and hit records are stored for some lanes of a tile only, so parts
-        // of a buffer are otherwise never written), and giving a buffer back at once and asking for it
-        // again.  The cause is not established.  The price is set-up time where the driver has to
-        // clear memory that was used before (25-40 GB/s: seconds for a set of 4K frames in a process
-        // that is not the machine's first).  RT_ALLOC_FILL=0 turns both off.
-        static const bool fill = !(getenv("RT_ALLOC_FILL") && atoi(getenv("RT_ALLOC_FILL")) == 0);
-        const bool lasting = fill && !transient && bytes >= (1u << 20);
-        if (e == hipSuccess && lasting && bytes >= ((size_t)64 << 20)) {
+        // A large buffer that lasts is written once from end to end before its first use.  Measured on
+        // MI355X (profiles/r3/alloc_experiment.txt, 150 steps of the 4K benchmark per process, six
+        // processes in a row on a freshly started machine): k_trace needs 11.6 ms per step on buffers
+        // that were never written as a whole (the arena is larger than what a frame fills, and hit
+        // records are stored for some lanes of a tile only) and 11.1-11.2 ms after one pass of writes -
+        // zeros or an arbitrary bit pattern alike, so it is not the data; in the machine's first
+        // process and in later ones alike, so it is not the driver's clearing of reused memory.  Giving
+        // the buffer back and asking again (which an earlier version did on top) adds nothing that
+        // can be told from run-to-run spread, and costs seconds of set-up.  RT_ALLOC_FILL=0 turns the
+        // pass off (2 and 3 bring the second allocation back, 4 writes the pattern).
+        const int mode = alloc_treatment();
+        const bool lasting = mode != 0 && !transient && bytes >= (1u << 20);
+        if (e == hipSuccess && lasting && (mode & 2) && mode < 4 && bytes >= ((size_t)64 << 20)) {
             (void)hipFree(p);
             p = nullptr;
             e = hipMalloc((void**)&p, bytes);
         }
-        if (e == hipSuccess && lasting) {
-            hipLaunchKernelGGL(k_fill_zero, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(p), bytes / 4);
-            e = hipDeviceSynchronize();
+        if (e == hipSuccess && lasting && ((mode & 1) || mode >= 4)) {
+            hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, g_alloc_stream, reinterpret_cast<uint32_t*>(p), bytes / 4,
+                               mode >= 4 ? 0x9e3779b9u : 0u);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(g_alloc_stream);
         }
         if (e == hipSuccess) n = count;
         return e;
@@ -217,6 +220,7 @@ struct RtContext {
     double* upload_scratch = nullptr;   // this GPU's g_upload_scratch (see upload_scratch_of)
 
     int precision = RT_PRECISION_MIXED;
+    bool frame_col32 = false;   // how the current frame's smooth arrays are stored (Dev::col32): chosen when its geometry starts
     bool profiling = false;
     struct Stamp { int kind; hipEvent_t t0, t1; };
     std::vector<Stamp> stamps;
@@ -234,6 +238,7 @@ struct RtContext {
         D.lvl_ntiles = lvl_ntiles.p; D.lvl_tilebase = lvl_tilebase.p; D.tile_run = tile_run.p; D.blk_tot = blk_tot.p; D.wave_off = wave_off.p;
         D.flags = flags.p; D.work = work.p;
         D.px = px.p; D.py = py.p; D.pz = pz.p; D.dx = dx.p; D.dy = dy.p; D.dz = dz.p; D.A = A.p; D.dist = dist.p;
+        D.col32 = frame_col32 ? 1 : 0;
         D.info = info.p; D.link = link.p; D.cr = cr.p; D.cg = cg.p; D.cb = cb.p; D.sr = sr.p; D.sg = sg.p; D.sb = sb.p;
         D.cap_tiles = (uint32_t)(arena_rays / TILE);
         D.lvl_shade_base = lvl_shade_base.p; D.list_ray = list_ray.p; D.list_node = list_node.p; D.redo_list = redo_list.p;
@@ -286,6 +291,7 @@ namespace {
 int use_device(RtContext* ctx) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
+    g_alloc_stream = ctx->stream;
     return RT_OK;
 }
 
@@ -299,8 +305,10 @@ size_t level_table_bytes(RtContext* ctx, int level) {
 hipError_t raise_dynamic_lds_limit() {
     const int most = MAX_LEVEL_NODES * LEVEL_TABLE_BYTES;
     if (hipError_t e = hipFuncSetAttribute((const void*)k_link, hipFuncAttributeMaxDynamicSharedMemorySize, most)) return e;
-    if (hipError_t e = hipFuncSetAttribute((const void*)k_combine<true>, hipFuncAttributeMaxDynamicSharedMemorySize, most)) return e;
-    return hipFuncSetAttribute((const void*)k_combine<false>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    if (hipError_t e = hipFuncSetAttribute((const void*)k_combine<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, most)) return e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)k_combine<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most)) return e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)k_combine<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most)) return e;
+    return hipFuncSetAttribute((const void*)k_combine<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
 }
 
 int launch_level(RtContext* ctx, int level) {
@@ -701,6 +709,7 @@ int rt_trace_level(RtContext* ctx, int32_t level) {
     if (level == 0) {
         // (re)start the frame on the pixels chosen by the last rt_begin_frame
         ctx->geometry_done = false;
+        ctx->frame_col32 = ctx->precision != RT_PRECISION_F64;   // k_trace, the lighting kernels and k_combine must agree
         ctx->begin(RT_K_INIT);
         hipLaunchKernelGGL(k_init, dim3(1), dim3(1024), 0, ctx->stream, ctx->dev());
         ctx->end();
@@ -882,9 +891,10 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     if (pos < 0 || pos > MT_N) return fail(RT_ERR_INVALID, "MT19937 position %d out of range", pos);
     // doubles to draw (two 32-bit outputs each): the whole image's stream
     const long long total = ctx->have_global_layout ? ctx->global_total : ctx->sample_total;
-    ctx->samples_delivered = ctx->sample_total;   // the whole stream of this context is made below
+    ctx->samples_delivered = 0;
     ctx->disk_points_ready = false;
     if (total == 0) {
+        ctx->samples_delivered = ctx->sample_total;
         memcpy(key_out, key, MT_N * sizeof(uint32_t));
         *pos_out = pos;
         return RT_OK;
@@ -966,6 +976,7 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         key_out[i] = (n > last_first ? ring : prev_ring)[n & (MT_RING - 1)];   // the last stream's own first word is not whole
     }
     *pos_out = (int32_t)(next - block * MT_N);
+    ctx->samples_delivered = ctx->sample_total;   // the whole stream of this context has been made
     // The raw words are only needed while they are being packed, but getting device memory back that
     // some process has used before takes the driver tens of milliseconds per GB (measured: 1.3 s for
     // the 50 GB of a 4K example_4 frame, every call), so a buffer of moderate size stays with the context.
@@ -989,7 +1000,8 @@ int rt_shade(RtContext* ctx) {
                     (long long)ctx->samples_delivered, (long long)ctx->sample_total);
     const Dev D = ctx->dev();
     const bool lds = ctx->S <= SHADE_LDS_SPHERES;
-    const bool mixed = ctx->precision != RT_PRECISION_F64 && ctx->sampled_lights && ctx->S <= MIXED_MAX_SPHERES && ctx->have_packed32;
+    // (the float32 sample pass stores float32 colours: only for frames whose geometry ran in mixed precision)
+    const bool mixed = ctx->precision != RT_PRECISION_F64 && ctx->frame_col32 && ctx->sampled_lights && ctx->S <= MIXED_MAX_SPHERES && ctx->have_packed32;
     const bool check = ctx->precision == RT_PRECISION_MIXED_CHECKED;
     if (mixed && !ctx->disk_points_ready) {
         // once per sample stream (not per frame): the float32 pass reads disk points, see k_disk_points
@@ -1008,16 +1020,17 @@ int rt_shade(RtContext* ctx) {
     else if (mixed && check) hipLaunchKernelGGL((k_surface_mixed<false, true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
     else if (mixed && ctx->simple_shading) hipLaunchKernelGGL((k_surface_mixed<true, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
     else if (mixed) hipLaunchKernelGGL((k_surface_mixed<false, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
-    else if (lds) hipLaunchKernelGGL((k_surface<true>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
-    else hipLaunchKernelGGL((k_surface<false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    else {
+        auto kernel = lds ? (D.col32 ? k_surface<true, true> : k_surface<true, false>) : (D.col32 ? k_surface<false, true> : k_surface<false, false>);
+        hipLaunchKernelGGL(kernel, dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
+    }
     if (mixed) hipLaunchKernelGGL((k_surface_redo<true>), dim3(64), dim3(BLOCK), 0, ctx->stream, D);
     ctx->end();
     for (int level = D.n_levels - 1; level >= 0; --level) {
         ctx->begin(RT_K_COMBINE);
-        if (ctx->S <= SPH_CHUNK_SMALL)
-            hipLaunchKernelGGL((k_combine<true>), dim3(ctx->nb), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
-        else
-            hipLaunchKernelGGL((k_combine<false>), dim3(ctx->nb), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
+        const bool small = ctx->S <= SPH_CHUNK_SMALL;
+        auto kernel = small ? (D.col32 ? k_combine<true, true> : k_combine<true, false>) : (D.col32 ? k_combine<false, true> : k_combine<false, false>);
+        hipLaunchKernelGGL(kernel, dim3(ctx->nb), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, D, level);
         ctx->end();
     }
     HIP_TRY(hipGetLastError());
@@ -1201,6 +1214,7 @@ int rt_debug_eval(RtContext* ctx, int32_t what, const double* in, double* out, i
             if (!(sph >= 0 && sph < ctx->S && sph == (double)(int)sph)) return fail(RT_ERR_INVALID, "row %lld: sphere index out of range", (long long)i);
         }
     DevBuf<double> d_in, d_out;
+    d_in.transient = d_out.transient = true;
     HIP_TRY(d_in.ensure((size_t)n * in_w));
     hipError_t e = d_out.ensure((size_t)n * out_w);
     if (e == hipSuccess) e = hipMemcpyAsync(d_in.p, in, (size_t)n * in_w * sizeof(double), hipMemcpyHostToDevice, ctx->stream);

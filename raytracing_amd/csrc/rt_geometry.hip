@@ -466,8 +466,8 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                 stream_store(d.x, &D.dx[idx]); stream_store(d.y, &D.dy[idx]); stream_store(d.z, &D.dz[idx]);
             }
             if (live) {
-                stream_store(A, &D.A[idx]);
-                if (b != 0 && trans && !inside) stream_store(through, &D.dist[idx]);   // k_combine reads it for these hits only
+                stream_store_smooth(D.A, idx, A, D.col32);
+                if (b != 0 && trans && !inside) stream_store_smooth(D.dist, idx, through, D.col32);   // k_combine reads it for these hits only
             }
         }
         if (valid) stream_store(info, &D.info[idx]);

@@ -27,7 +27,7 @@ struct CombineTile {   // first stage of the pipeline: what is known / requested
     uint32_t info;
     unsigned trun;     // lanes 0-2: running child counts at the tile's start
 };
-template <bool SMALL>   // SMALL: at most SPH_CHUNK_SMALL spheres, their constants in LDS
+template <bool SMALL, bool C32>   // SMALL: at most SPH_CHUNK_SMALL spheres, their constants in LDS; C32: colours, A, dist kept as float32
 __global__ __launch_bounds__(BLOCK, RT_COMBINE_WAVES) void k_combine(Dev D, int level) {
     extern __shared__ int s_dyn[];
     __shared__ CombineSphere s_cs[SMALL ? SPH_CHUNK_SMALL : 1];
@@ -100,9 +100,17 @@ __global__ __launch_bounds__(BLOCK, RT_COMBINE_WAVES) void k_combine(Dev D, int 
 
     // One pipeline step: second set of loads for the group `cur`, then the first set of the group
     // after it (into `nxt`), then arithmetic and stores for `cur`.
+    // Loaded values stay in registers of the stored type until the arithmetic: a conversion at the
+    // load would make the wave wait for that load at once.
+    typedef typename SmoothType<C32>::type Stored;
+    struct Stored3 { Stored x, y, z; };
+    auto load3 = [](const double* bx, const double* by, const double* bz, uint32_t i) -> Stored3 {
+        return {reinterpret_cast<const Stored*>(bx)[i], reinterpret_cast<const Stored*>(by)[i], reinterpret_cast<const Stored*>(bz)[i]};
+    };
+    auto widen = [](const Stored3& v) -> V3 { return {(double)v.x, (double)v.y, (double)v.z}; };
     auto step = [&](const CombineTile (&cur)[COMBINE_TILES], CombineTile (&nxt)[COMBINE_TILES]) {
-        double A[COMBINE_TILES], through[COMBINE_TILES];
-        V3 surf[COMBINE_TILES], refr[COMBINE_TILES], refl[COMBINE_TILES];
+        Stored A[COMBINE_TILES], through[COMBINE_TILES];
+        Stored3 surf[COMBINE_TILES], refr[COMBINE_TILES], refl[COMBINE_TILES];
 #pragma unroll
         for (int u = 0; u < COMBINE_TILES; ++u) {
             const uint32_t idx = (uint32_t)(tbase + max(cur[u].t, 0)) * TILE + lane;
@@ -124,16 +132,16 @@ __global__ __launch_bounds__(BLOCK, RT_COMBINE_WAVES) void k_combine(Dev D, int 
             if (lit != 0)
                 entry = (uint32_t)shade_base + LANE((int)(wave_base + cur[u].trun), C_SHADE) + lanes_below(lit);
             if ((in & I_LIVE) && is_hit(in)) {
-                A[u] = D.A[idx];
-                if (in & I_SHADE) surf[u] = {D.sr[entry], D.sg[entry], D.sb[entry]};
+                A[u] = reinterpret_cast<const Stored*>(D.A)[idx];
+                if (in & I_SHADE) surf[u] = load3(D.sr, D.sg, D.sb, entry);
                 if (want_ti) {
                     const uint32_t sl = (in & I_CHILD_T) ? slot[C_T] : slot[C_I];
-                    refr[u] = {D.cr[sl], D.cg[sl], D.cb[sl]};
-                    if ((in & I_CHILD_T) && !(in & I_INSIDE)) through[u] = D.dist[idx];
+                    refr[u] = load3(D.cr, D.cg, D.cb, sl);
+                    if ((in & I_CHILD_T) && !(in & I_INSIDE)) through[u] = reinterpret_cast<const Stored*>(D.dist)[idx];
                 }
                 if (want_r) {
                     const uint32_t sl = slot[C_R];
-                    refl[u] = {D.cr[sl], D.cg[sl], D.cb[sl]};
+                    refl[u] = load3(D.cr, D.cg, D.cb, sl);
                 }
             }
         }
@@ -150,20 +158,22 @@ __global__ __launch_bounds__(BLOCK, RT_COMBINE_WAVES) void k_combine(Dev D, int 
                 if (is_hit(in)) {
                     const int sid = in & I_SID_MASK;
                     const CombineSphere cs = SMALL ? s_cs[sid] : sphere_consts(sid);
-                    V3 rf = refr[u];
+                    V3 rf = widen(refr[u]);
+                    const double a = (double)A[u];
                     if ((in & I_LIVE_TI) && (in & I_CHILD_T) && !(in & I_INSIDE)) {
                         // absorption inside the entered sphere (reference raytrace.py:119-120)
-                        rf.x *= exp(cs.kr * through[u]);
-                        rf.y *= exp(cs.kg * through[u]);
-                        rf.z *= exp(cs.kb * through[u]);
+                        const double len = (double)through[u];
+                        rf.x *= exp(cs.kr * len);
+                        rf.y *= exp(cs.kg * len);
+                        rf.z *= exp(cs.kb * len);
                     }
-                    col = clip01(((1 - cs.tr) * (1 - A[u])) * surf[u] + (cs.tr * (1 - A[u])) * rf + A[u] * refl[u]);
+                    col = clip01(((1 - cs.tr) * (1 - a)) * widen(surf[u]) + (cs.tr * (1 - a)) * rf + a * widen(refl[u]));
                 }
                 if (level == 0) {   // a primary ray's colour is the pixel; no parent reads it
                     double* out = D.image + (size_t)(cur[u].first + lane) * 3;
                     out[0] = col.x; out[1] = col.y; out[2] = col.z;
                 } else {
-                    D.cr[idx] = col.x; D.cg[idx] = col.y; D.cb[idx] = col.z;
+                    store_smooth(D.cr, idx, col.x, C32); store_smooth(D.cg, idx, col.y, C32); store_smooth(D.cb, idx, col.z, C32);
                 }
             }
         }

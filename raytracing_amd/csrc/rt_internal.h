@@ -124,6 +124,8 @@ struct Dev {
     double *dist;           // path length inside the entered sphere (0: no attenuation)
     uint32_t* info;
     uint32_t* link;         // arena index of the parent ray
+    int32_t col32;          // the arrays A, dist, cr..cb, sr..sb hold float32 values (mixed precision) instead of
+                            // float64: smooth quantities no hit / miss decision depends on (load_smooth / store_smooth)
     double *cr, *cg, *cb;   // ray colour (after k_combine)
     double *sr, *sg, *sb;   // surface colour of shading-list entry e (after the lighting kernels): dense, so that
                             // the lighting kernels store and k_combine reads whole lines

@@ -256,7 +256,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
 
 // ---------------------------------------------------------------------------------------------
 // Lighting in float64 for the dense list of hits whose surface colour matters (all levels).
-template <bool LDS>
+template <bool LDS, bool C32>   // C32: surface colours stored as float32 (Dev::col32)
 __global__ __launch_bounds__(BLOCK, LDS ? RT_SURFACE_WAVES : RT_SURFACE_WAVES_MANY) void k_surface(Dev D) {
     constexpr int TABLE = LDS ? SHADE_LDS_SPHERES : 1;
     __shared__ ShadowSphere s_sh[TABLE];
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(BLOCK, LDS ? RT_SURFACE_WAVES : RT_SURFACE_WAVES_MA
         const Surface sf = surface_at(P, centre, info & I_INSIDE, eps);
         V3 surf = surface_color<LDS>(D, sc, s_sh, lists, e, info, sf.Pb, d, sf.n, mat, my_samples);
         my_hits += 1;
-        D.sr[e] = surf.x; D.sg[e] = surf.y; D.sb[e] = surf.z;
+        store_smooth(D.sr, e, surf.x, C32); store_smooth(D.sg, e, surf.y, C32); store_smooth(D.sb, e, surf.z, C32);
         e = e_next;
         ray = ray_next;
     }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(BLOCK) void k_surface_redo(Dev D) {
         unsigned a = 0;
         V3 surf = surface_color<LDS>(D, sc, s_sh, lists, e, info, sf.Pb, d, sf.n,
                                      surface_material(D.mat + (size_t)sid * RT_MAT_WIDTH), a);
-        D.sr[e] = surf.x; D.sg[e] = surf.y; D.sb[e] = surf.z;
+        store_smooth(D.sr, e, surf.x, true); store_smooth(D.sg, e, surf.y, true); store_smooth(D.sb, e, surf.z, true);   // follows the float32 sample pass: mixed precision
     }
 }
 

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
         if (active) {
             my_hits += 1;
             my_samples += hit_samples;
-            D.sr[e] = surf.x; D.sg[e] = surf.y; D.sb[e] = surf.z;
+            store_smooth(D.sr, e, surf.x, true); store_smooth(D.sg, e, surf.y, true); store_smooth(D.sb, e, surf.z, true);   // this pass only runs in mixed precision (D.col32)
             if (redo) {
                 // some shadow decision of this hit could not be certified in float32 (or the hit had more
                 // candidate spheres than the sample loop holds): k_surface_redo evaluates the hit again

@@ -15,6 +15,24 @@ __device__ __forceinline__ void stream_store(T v, T* p) { __builtin_nontemporal_
 struct V3 {
     double x, y, z;
 };
+
+// Colours, reflected fractions and in-sphere path lengths are smooth quantities: no hit / miss
+// decision, count or random-stream address depends on them.  In mixed precision their arrays hold
+// float32 values (half the bytes through the colour pass), in float64 mode doubles; the arithmetic on
+// them is float64 either way.  `f32` is uniform over the launch.
+template <bool F32> struct SmoothType { typedef double type; };
+template <> struct SmoothType<true> { typedef float type; };
+__device__ __forceinline__ double load_smooth(const double* base, uint32_t i, bool f32) {
+    return f32 ? (double)reinterpret_cast<const float*>(base)[i] : base[i];
+}
+__device__ __forceinline__ void store_smooth(double* base, uint32_t i, double v, bool f32) {
+    if (f32) reinterpret_cast<float*>(base)[i] = (float)v;
+    else base[i] = v;
+}
+__device__ __forceinline__ void stream_store_smooth(double* base, uint32_t i, double v, bool f32) {
+    if (f32) __builtin_nontemporal_store((float)v, reinterpret_cast<float*>(base) + i);
+    else __builtin_nontemporal_store(v, base + i);
+}
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }

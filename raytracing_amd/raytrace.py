@@ -154,8 +154,12 @@ class Renderer:
         return self.ctx.counters()
 
 
-def raytrace(scene, *, params=None, device=0, precision="mixed", sampler="auto"):
+def raytrace(scene, *, params=None, device=0, devices=None, precision="mixed", sampler="auto"):
     """Render ``scene``; returns a ``(height, width, 3)`` float64 image in [0, 1].
+
+    ``devices``: a list of GPU indices renders the frame split into row blocks on those GPUs, one
+    process per GPU, started (and joined) by this call - see :mod:`raytracing_amd.launcher`; the
+    image comes back to the caller and NumPy's global stream is left as after a single-GPU call.
 
     Same meaning as the reference's ``raytrace(scene)`` (reference
     raytrace.py:273-279).  The image size and depth limits come from ``params``
@@ -166,8 +170,14 @@ def raytrace(scene, *, params=None, device=0, precision="mixed", sampler="auto")
 
     ``precision``: ``"mixed"`` (default) evaluates disk-light samples in float32
     with float64 re-evaluation of every shadow decision it cannot certify;
-    ``"f64"`` evaluates them in float64 like the reference.  Everything else is
-    float64 in both modes."""
+    ``"f64"`` evaluates them in float64 like the reference.  Mixed precision also keeps the
+    colours that travel between the levels of the recursion as float32; every hit / miss
+    decision, count and random-stream address is float64 in both modes."""
+    if devices is not None and len(devices) > 1:
+        from .launcher import raytrace_on_devices
+        return raytrace_on_devices(scene, devices, params=params, precision=precision)
+    if devices is not None and len(devices) == 1:
+        device = devices[0]
     with Renderer(scene, params, device, precision=precision, sampler=sampler) as r:
         r.begin_rows(0, r.params.height)
         img = r.render_pixels()

@@ -5,7 +5,9 @@ Tolerances: geometry is float64 in the reference's own rounding order, so ray /
 hit / in-beam counts must match exactly and images of the float64 mode agree
 with the reference to rounding noise (asserted: 1e-8 per channel).  The default
 mixed mode evaluates disk-light samples in float32 with certified shadow
-decisions; its images are held to 2e-5 per channel (the stated requirement is
+decisions and keeps the colours that travel between the levels of the recursion
+(and the reflected fractions and in-sphere path lengths that weight them) as
+float32; its images are held to 2e-5 per channel (the stated requirement is
 1e-4)."""
 import os
 
@@ -124,7 +126,7 @@ def test_row_strips_through_get_pixel_color(golden_dir):
         rows = []
         for r0, r1 in zip(bounds[:-1], bounds[1:]):
             Y, X = np.indices((r1 - r0, 160), dtype=float)
-            rows.append(get_pixel_color(X.reshape(-1, 1), (Y + r0).reshape(-1, 1), scene).reshape(r1 - r0, 160, 3))
+            rows.append(get_pixel_color(X.reshape(-1, 1), (Y + r0).reshape(-1, 1), scene, precision="f64").reshape(r1 - r0, 160, 3))
         assert np.abs(np.concatenate(rows) - g[name + "_strips"]).max() <= TOL
 
 
@@ -156,7 +158,7 @@ def test_tiny_frames_and_the_small_batch_rule():
         assert np.array_equal(get_pixel_color(X, Y, scene), np.tile(bg, (n, 1)))
     X = np.array([80.0, 80.0, 81.0, 10.0])[:, None]
     Y = np.array([60.0, 60.5, 60.0, 2.0])[:, None]
-    got = get_pixel_color(X, Y, scene)
+    got = get_pixel_color(X, Y, scene, precision="f64")
     flat_params = RenderParams(width=160, height=90)
     want = O.Oracle(__import__("raytracing_amd.flatten", fromlist=["x"]).flatten_scene(scene), flat_params).pixel_colors(X, Y)
     assert np.abs(got - want).max() <= TOL
@@ -236,31 +238,34 @@ def test_batch_sizes_in_caller_owned_device_memory(golden_dir):
 
 # ---------------------------------------------------------------------------------------------
 # Branches the example scenes hardly reach, on fixtures made by running the reference.
-def test_total_internal_reflection_scene(golden_dir):
+@pytest.mark.parametrize("precision,tol", PRECISIONS)
+def test_total_internal_reflection_scene(golden_dir, precision, tol):
     """reference raytrace.py:122-127: ~4000 rays in calls reached through the "i" branch (camera
     inside a glass sphere, a sphere of index 0.8, overlapping glass spheres)."""
     g = _load(golden_dir, "tir_160x90.npz")
     tir = [int(n) for p, n in zip(g["trace_path"], g["trace_rays"]) if str(p).endswith("i") and n >= 3]
     assert sum(tir) >= 1000
-    img, tree, batch, hits, beam, cnt = _render(synthetic.tir_scene(160, 90))
-    assert np.abs(img - g["image"]).max() <= TOL
+    img, tree, batch, hits, beam, cnt = _render(synthetic.tir_scene(160, 90), precision=precision)
+    assert np.abs(img - g["image"]).max() <= tol
     _check_counts(tree, batch, hits, beam, g, "trace")
     paths = _paths(tree)
     assert sum(int(batch[k]) for k in range(tree.n_nodes) if paths[k].endswith("i") and batch[k] >= 3) == sum(tir)
 
 
-def test_attenuation_above_one_and_the_per_call_clip(golden_dir):
+@pytest.mark.parametrize("precision,tol", PRECISIONS)
+def test_attenuation_above_one_and_the_per_call_clip(golden_dir, precision, tol):
     """reference raytrace.py:117-120: a transmitted ray that misses the sphere it entered gets the
     path length -1, so its colour is multiplied by exp(+k) > 1; reference raytrace.py:170 clips the
     result of every call, also below the top level (the fixture records values up to 11 entering
     that clip at depth).  A forward accumulation of path weights would differ here; the bottom-up
-    colour pass reproduces the reference."""
+    colour pass reproduces the reference.  In mixed precision the colours between the calls are
+    float32: every one of them has passed the clip, so they lie in [0, 1] whatever entered it."""
     g = _load(golden_dir, "clip_160x90.npz")
     deep = [m for (a, b), m in zip(g["preclip_depth_used"], g["preclip_max"]) if a + b > 0]
     assert max(deep) > 2.0
     params = RenderParams(width=160, height=90, epsilon=float(g["epsilon"]))
-    img, tree, batch, hits, beam, cnt = _render(synthetic.clip_scene(160, 90), params)
-    assert np.abs(img - g["image"]).max() <= TOL
+    img, tree, batch, hits, beam, cnt = _render(synthetic.clip_scene(160, 90), params, precision=precision)
+    assert np.abs(img - g["image"]).max() <= tol
     _check_counts(tree, batch, hits, beam, g, "trace")
 
 
@@ -349,14 +354,20 @@ def test_full_hd_counts_equal_the_reference_run(name):
 # The reference's output step: 8-bit images, quantised on the GPU, against what the reference
 # wrote through plt.imsave (goldens made by tests/golden/make_golden.py, generator "rgb8").
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision,max_levels_off", [("f64", 0.0), ("mixed", 5e-3)])
 @pytest.mark.parametrize("name", ["example_1", "example_2", "example_3"])
-def test_rgb8_equals_reference_output(golden_dir, name):
+def test_rgb8_equals_reference_output(golden_dir, name, precision, max_levels_off):
+    """Float64: the reference's bytes.  Mixed precision (colours between the recursion's calls kept
+    as float32, within 2e-5 of the reference): a channel may land on the other side of a
+    quantisation step, never further than one level."""
     from raytracing_amd.raytrace import raytrace_rgb8
     gold = _load(golden_dir, "rgb8.npz")[name]
     h, w, _ = gold.shape
-    got = raytrace_rgb8(build_scene(name, w, h))
+    got = raytrace_rgb8(build_scene(name, w, h), precision=precision)
     assert got.dtype == np.uint8 and got.shape == gold.shape
-    assert (got == gold).all()
+    diff = np.abs(got.astype(int) - gold.astype(int))
+    assert diff.max() <= (1 if max_levels_off else 0)
+    assert (diff > 0).mean() <= max_levels_off
 
 
 @pytest.mark.gpu
@@ -735,3 +746,126 @@ def test_certified_float32_shadow_decisions_equal_float64(name):
     assert cnt["fallback_samples"] <= 0.05 * cnt["shaded_samples"], (cnt["fallback_samples"], cnt["shaded_samples"])
     plain = _render(scene, seed=5, precision="mixed")
     assert np.array_equal(plain[0], got)
+
+
+# ---------------------------------------------------------------------------------------------
+# The soft-shadow configuration at its benchmark size: a spotlight with 64 samples per hit, one frame
+# per easing mode, 3840x2160.  The reference needs minutes for 128x72 of it, so the full-size frames are
+# held to properties: pixel (30 x, 30 y) of the big frame is the same ray as pixel (x, y) of the 128x72
+# golden (reference objects.py:45-51 places pixel X at X * width / WIDTH, no half-pixel offset), so that
+# sub-grid must equal the golden up to the noise of 64 differently drawn light samples; the geometry does
+# not depend on the easing mode; rays, hits and in-beam hits per pixel are the golden's up to the sampling
+# density; the stream length is 2 * 64 * in-beam hits; rendering again reproduces the frame; the 8-bit
+# frame is the quantised one; the float32 sample pass stays within 2e-5 of the float64 one.
+SPOT_MODES = ["linear", "quadratic", "cubic", "exponential"]
+
+
+@pytest.mark.gpu
+def test_spotlight_frames_at_benchmark_size(golden_dir):
+    from raytracing_amd.imageio import quantise
+    g = _load(golden_dir, "spot_128x72.npz")
+    W, H = 3840, 2160
+    counts = {}
+    for mode in SPOT_MODES:
+        scene = synthetic.spotlight_scene(mode, 64, W, H)
+        imgs = {}
+        for precision in ("mixed", "f64"):
+            np.random.seed(0)
+            with Renderer(scene, precision=precision) as r:
+                r.begin_rows(0, H)
+                r.trace()
+                n_uniforms = r.draw_samples()
+                r.shade()
+                img = r.image().reshape(H, W, 3).copy()
+                cnt = r.counters()
+                if precision == "mixed":
+                    rgb8 = r.ctx.read_image_rgb8().reshape(H, W, 3).copy()
+                    r.ctx.trace_geometry()
+                    r.ctx.shade()
+                    assert np.array_equal(r.image().reshape(H, W, 3), img)
+                    assert np.array_equal(rgb8, quantise(img))
+                    in_beam = int(r.node_beam[:, 0].sum())
+                    assert n_uniforms == 2 * 64 * in_beam
+                    counts[mode] = (int(cnt["rays"]), int(cnt["hits"]), in_beam)
+                    assert 0 <= cnt["fallback_samples"] < 1e-3 * cnt["shaded_samples"]
+            imgs[precision] = img
+        assert imgs["f64"].min() >= 0.0 and imgs["f64"].max() <= 1.0
+        assert np.abs(imgs["mixed"] - imgs["f64"]).max() <= TOL_MIXED
+        # the sub-grid of rays the golden frame consists of: same scene, other random numbers
+        # (measured: mean difference 5e-3, 99th percentile 3e-2, largest 8e-2 - the spread of a mean of 64 samples)
+        diff = np.abs(imgs["f64"][::30, ::30] - g[mode + "_image"])
+        assert diff.mean() < 1e-2 and np.quantile(diff, 0.99) < 6e-2 and diff.max() < 0.2, (mode, diff.mean(), np.quantile(diff, 0.99), diff.max())
+        rays, hits, beam = g[mode + "_rays"], g[mode + "_hits"], g[mode + "_beam"]
+        want = np.array([rays[rays >= 3].sum(), hits.sum(), beam[:, 0].sum()]) / (128 * 72)
+        got = np.array(counts[mode]) / (W * H)
+        assert np.abs(got / want - 1.0).max() < 1e-2, (mode, got, want)
+    assert len(set(counts.values())) == 1          # easing changes the light, not the geometry
+
+
+# ---------------------------------------------------------------------------------------------
+# The frame the multi-GPU scaling target is quoted on, example_4 at 7680x4320, on one GPU.  Same kind of
+# properties: pixel (48 x, 48 y) is the ray of pixel (x, y) of the 160x90 golden (other random numbers
+# for the disk light); the stream length is 2 * 30 * hits; a sky pixel is exactly the background; a
+# second render reproduces the frame; the 8-bit frame is the quantised one; and rows 2000-2539 rendered
+# on their own - given the whole frame's batch sizes (small-batch rule) and their columns of the whole
+# frame's random stream, which is what one GPU of several does - equal the whole frame bit for bit.
+@pytest.mark.gpu
+def test_example_4_at_7680x4320_and_a_540_row_block(golden_dir):
+    from raytracing_amd.imageio import quantise
+    from raytracing_amd.tree import sample_offsets
+    g = _load(golden_dir, "images_160x90.npz")
+    W, H = 7680, 4320
+    R0, ROWS = 2000, 540
+    scene = build_scene("example_4", W, H)
+    np.random.seed(0)
+    state0 = np.random.get_state()
+    with Renderer(scene) as r:
+        r.begin_rows(0, H)
+        r.trace()
+        n_uniforms = r.draw_samples()
+        r.shade()
+        cnt = r.counters()
+        block = r.image().reshape(H, W, 3)[R0:R0 + ROWS].copy()
+        sub = r.image().reshape(H, W, 3)[::48, ::48].copy()
+        rgb8_rows = r.ctx.read_image_rgb8().reshape(H, W, 3)[R0:R0 + ROWS].copy()
+        whole_batches = [r.ctx.level_batches(level) for level in range(r.tree.n_levels)]
+        whole_hits, whole_beam = r.node_hits.copy(), r.node_beam.copy()
+        state_after = np.random.get_state()
+        r.ctx.trace_geometry()
+        r.ctx.shade()
+        assert np.array_equal(r.image().reshape(H, W, 3)[R0:R0 + ROWS], block)
+        tree, lights = r.tree, r.flat.lights
+    assert n_uniforms == 2 * 30 * int(cnt["hits"])
+    assert np.array_equal(rgb8_rows, quantise(block))
+    assert np.all(sub[0, 0] == np.array([0.251, 0.624, 0.769]))
+    per_pixel = cnt["rays"] / (W * H)
+    assert abs(per_pixel / (FULL_HD_REFERENCE_COUNTS["example_4"]["rays"] / (1920 * 1080)) - 1.0) < 2e-3
+    diff = np.abs(sub - g["example_4_image"])
+    assert diff.mean() < 1e-2 and np.quantile(diff, 0.99) < 6e-2 and diff.max() < 0.2, (diff.mean(), np.quantile(diff, 0.99), diff.max())
+
+    def geometry_of_rows(r, row0, n_rows):
+        arena = 24 * n_rows * W
+        while True:                                     # rows through the spheres need more rays per pixel than the frame's mean
+            r.begin_rows(row0, n_rows, arena_rays=arena)
+            for level in range(r.tree.n_levels):
+                if level:
+                    r.ctx.set_global_batches(level, whole_batches[level])
+                r.ctx.trace_level(level)
+            try:
+                return r.ctx.node_counts()
+            except _native.RtOverflow:
+                arena *= 2
+
+    with Renderer(scene) as above:                      # rows before the block: how many hits of every node precede it
+        _, first_hits, _ = geometry_of_rows(above, 0, R0)
+    with Renderer(scene) as part:
+        _, hits, beam = geometry_of_rows(part, R0, ROWS)
+        g_off, g_cnt, g_total = sample_offsets(tree, lights, whole_hits, whole_beam)
+        l_off, _, l_total = sample_offsets(tree, lights, hits, beam)
+        assert g_total == n_uniforms
+        part.ctx.set_sample_layout(l_off, l_total)
+        part.ctx.set_sample_layout_global(g_off, g_cnt, first_hits[:, None].repeat(len(lights), axis=1), g_total)
+        key, pos = part.ctx.generate_samples(state0[1], state0[2])
+        assert pos == state_after[2] and np.array_equal(key, state_after[1])
+        part.ctx.shade()
+        assert np.array_equal(part.ctx.read_image().reshape(ROWS, W, 3), block)

@@ -52,6 +52,33 @@ def test_noalloc_upload_matches_the_allocating_one(precision):
     assert np.array_equal(small, small_ref)
 
 
+def test_noalloc_upload_leaves_free_device_memory_unchanged():
+    """hipMemGetInfo before and after the calls: the allocating entry point grows its staging
+    buffer on the first call of a context, the other one takes nothing."""
+    import torch
+    flat = flatten_scene(build_scene("example_4", 160, 90))
+    params = RenderParams(width=160, height=90)
+    tree = build_tree(params.max_reflection_depth, params.max_refraction_depth)
+    u = np.random.RandomState(1).random_sample(_native.NOALLOC_MAX_SAMPLES)
+    with _native.Context(0) as ctx:
+        ctx.set_scene(flat, params, tree)
+        ctx.begin_rows(0, 90, 160)
+        ctx.trace_geometry()
+        _, hits, beam = ctx.node_counts()
+        offsets, _, total = sample_offsets(tree, flat.lights, hits, beam)
+        ctx.set_sample_layout(offsets, total)
+        assert total > 2 * u.size
+        ctx.synchronize()
+        free_before = torch.cuda.mem_get_info(0)[0]
+        ctx.upload_samples_noalloc(0, u)
+        ctx.upload_samples_noalloc(u.size, u[:12345])
+        ctx.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] == free_before
+        ctx.upload_samples(0, u)                       # control: this one allocates its staging buffer
+        ctx.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] < free_before
+
+
 def test_noalloc_upload_refuses_more_than_its_array_holds():
     flat = flatten_scene(build_scene("example_4", 160, 90))
     params = RenderParams(width=160, height=90)
