@@ -656,6 +656,8 @@ class FrameSet:
                               n_buffers=2 if self.pipelined else 1)
                      for f, name in enumerate(scene_names)]
         self.graphs = None
+        # one GPU: frames as independent pipelines (RT_FRAME_PIPELINES=0: one graph per step that joins the frames)
+        self.frame_pipelines = os.environ.get("RT_FRAME_PIPELINES", "1") != "0"
         self.steps_issued = 0
         self.tiles_sent = [None, None]        # event per output buffer: its last transfer has finished
         self.speculate = self.pipelined and os.environ.get("RT_SPECULATE", "1") != "0"
@@ -730,10 +732,25 @@ class FrameSet:
             job.ctx.set_batch_guess(None)
         return body
 
+    def _captured_frame(self, job):
+        """One frame's whole step as a graph of its own, captured on (and replayed into) the frame's stream."""
+        torch = self.torch
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(job.stream):
+            g.capture_begin(capture_error_mode="relaxed")
+            try:
+                self._whole(job)
+            finally:
+                g.capture_end()
+        return g
+
     def capture(self):
         try:
             if not self.sharded:
-                self.graphs = {"step": self._captured(self._whole)}
+                if self.frame_pipelines:
+                    self.graphs = {"frames": [self._captured_frame(job) for job in self.jobs]}
+                else:
+                    self.graphs = {"step": self._captured(self._whole)}
             else:
                 self.graphs = {"level": [self._captured(self._level(l)) for l in range(self.jobs[0].n_levels)],
                                "shade": [self._captured(self._shade(b)) for b in range(2)]}
@@ -762,6 +779,17 @@ class FrameSet:
                     job.step_level(level)
             for job in self.jobs:
                 job.step_finish()
+            return
+        if not self.sharded and self.frame_pipelines:
+            # every frame is a pipeline of its own: its step k + 1 follows its step k on the frame's
+            # stream and waits for no other frame, so a frame with a short chain of kernels does not
+            # idle until the longest one has finished the step
+            for f, job in enumerate(self.jobs):
+                with torch.cuda.stream(job.stream):
+                    if self.graphs is not None:
+                        self.graphs["frames"][f].replay()
+                    else:
+                        self._whole(job)
             return
         if not self.sharded:
             with torch.cuda.stream(self.stream):
