@@ -14,6 +14,7 @@
 #include "mt_jump.h"
 #include "rt_kernels.hip"
 #include "hier_build.h"
+#include "grid_build.h"
 
 using namespace rt;
 
@@ -170,6 +171,12 @@ struct RtContext {
     DevBuf<uint16_t> hier_ids;
     int hier_top_groups = 0, hier_blocks = 0;
     float hier_window = 0, hier_extent = 0;
+    DevBuf<uint32_t> grid_start;
+    DevBuf<uint16_t> grid_items, grid_loose;
+    DevBuf<float> grid_sph;
+    int grid_cells = 0, grid_n_loose = 0, grid_n[3] = {0, 0, 0};
+    float grid_h = 0, grid_inv_h = 0;
+    double grid_origin[3] = {0, 0, 0}, grid_hi[3] = {0, 0, 0};
     DevBuf<SceneConst> sc;
     DevBuf<int32_t> node_a, node_b, node_branch, node_child, level_start;
     DevBuf<int32_t> node_n, node_nglobal, node_hits, node_beam, node_tile0, node_ntiles, lvl_ntiles, lvl_tilebase, flags;
@@ -231,6 +238,9 @@ struct RtContext {
         Dev D{};
         D.geom = geom.p; D.mat = mat.p; D.fres = fres.p; D.cull = cull.p; D.cull_ref[0] = cull_ref[0]; D.cull_ref[1] = cull_ref[1]; D.cull_ref[2] = cull_ref[2]; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
         D.hier_top = hier_top.p; D.hier_top_ref = hier_top_ref.p; D.hier_mid = hier_mid.p; D.hier_leaf = hier_leaf.p; D.hier_ids = hier_ids.p; D.hier_top_groups = hier_top_groups; D.hier_blocks = hier_blocks; D.hier_window = hier_window; D.hier_extent = hier_extent;
+        D.grid_start = grid_start.p; D.grid_items = grid_items.p; D.grid_sph = reinterpret_cast<const float4*>(grid_sph.p); D.grid_loose = grid_loose.p;
+        D.grid_n_loose = grid_n_loose; D.grid_cells = grid_cells; D.grid_h = grid_h; D.grid_inv_h = grid_inv_h;
+        for (int k = 0; k < 3; ++k) { D.grid_n[k] = grid_n[k]; D.grid_origin[k] = grid_origin[k]; D.grid_hi[k] = grid_hi[k]; }
         D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
         D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.nb = nb; D.node_nguess = batch_guess; D.batch_slot = batch_slot; D.batch_slots = batch_slots; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
@@ -443,7 +453,7 @@ void rt_destroy(RtContext* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->collect();
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
-    ctx->geom.release(); ctx->mat.release(); ctx->fres.release(); ctx->cull.release(); ctx->hier_top.release(); ctx->hier_mid.release(); ctx->hier_leaf.release(); ctx->hier_top_ref.release(); ctx->hier_ids.release(); ctx->sc.release();
+    ctx->geom.release(); ctx->mat.release(); ctx->fres.release(); ctx->cull.release(); ctx->hier_top.release(); ctx->hier_mid.release(); ctx->hier_leaf.release(); ctx->hier_top_ref.release(); ctx->hier_ids.release(); ctx->grid_start.release(); ctx->grid_items.release(); ctx->grid_loose.release(); ctx->grid_sph.release(); ctx->sc.release();
     ctx->node_a.release(); ctx->node_b.release(); ctx->node_branch.release(); ctx->node_child.release();
     ctx->level_start.release(); ctx->node_n.release(); ctx->node_nglobal.release(); ctx->node_hits.release();
     ctx->node_beam.release(); ctx->node_tile0.release(); ctx->node_ntiles.release(); ctx->lvl_ntiles.release();
@@ -563,10 +573,33 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
         }
         HIP_TRY(ctx->cull.ensure(n_pairs * 10));
         HIP_TRY(hipMemcpy(ctx->cull.p, cull.data(), n_pairs * sizeof(CullPair), hipMemcpyHostToDevice));
-        // bounding-sphere hierarchy above that table (RT_HIERARCHY=0: screen every sphere for every ray)
+        // Above that table (RT_HIERARCHY=0: neither, every sphere is screened for every ray): a uniform grid
+        // over the spheres, or (RT_ACCEL=hier, or more than GRID_MAX_LOOSE spheres that do not fit a grid)
+        // a bounding-sphere hierarchy.  RT_GRID_DENSITY: cells per sphere the grid aims at.
         ctx->hier_top_groups = 0;
+        ctx->grid_cells = 0;
         const char* use_hier = getenv("RT_HIERARCHY");
-        if (S > SPH_CHUNK_SMALL && !(use_hier && use_hier[0] == '0')) {
+        const char* accel = getenv("RT_ACCEL");
+        const bool accelerate = S > SPH_CHUNK_SMALL && !(use_hier && use_hier[0] == '0');
+        if (accelerate && !(accel && strcmp(accel, "hier") == 0)) {
+            const char* dens = getenv("RT_GRID_DENSITY");
+            const HostGrid G = build_grid(scene->sphere_geom, S, dens ? atof(dens) : 2.0);
+            if (!G.start.empty() && G.loose.size() <= (size_t)GRID_MAX_LOOSE) {
+                auto upload = [](auto& buf, const auto& v) -> hipError_t {
+                    if (hipError_t e = buf.ensure(std::max<size_t>(2, v.size()))) return e;
+                    return v.empty() ? hipSuccess : hipMemcpy(buf.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice);
+                };
+                HIP_TRY(upload(ctx->grid_start, G.start));
+                HIP_TRY(upload(ctx->grid_items, G.items));
+                HIP_TRY(upload(ctx->grid_sph, G.sph));
+                HIP_TRY(upload(ctx->grid_loose, G.loose));
+                ctx->grid_cells = G.cells();
+                ctx->grid_n_loose = (int)G.loose.size();
+                ctx->grid_h = G.h; ctx->grid_inv_h = G.inv_h;
+                for (int k = 0; k < 3; ++k) { ctx->grid_n[k] = G.n[k]; ctx->grid_origin[k] = G.origin[k]; ctx->grid_hi[k] = G.hi[k]; }
+            }
+        }
+        if (accelerate && ctx->grid_cells == 0) {
             const HostHierarchy H = build_hierarchy(scene->sphere_geom, S);
             auto upload = [](auto& buf, const auto& v) -> hipError_t {
                 if (hipError_t e = buf.ensure(std::max<size_t>(1, v.size()))) return e;

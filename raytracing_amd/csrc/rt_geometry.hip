@@ -334,7 +334,37 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
             };
             const LaneList list = {&s_list[0][SMALL ? 0 : tid]}, clusters = {&s_list[SMALL ? 0 : HIER_CAP][SMALL ? 0 : tid]};
             bool every_sphere = active;   // lanes that screen the whole table
-            if (D.hier_top_groups) {
+            if (D.grid_cells) {
+                // Uniform grid: the spheres outside it first (a hit there bounds the walk), then the
+                // cells along the ray, front to back.  Candidates collect in the lane's list and take
+                // the float64 test together, every few steps or when some lane's list is nearly full; a
+                // lane's walk ends at the first cell that begins beyond the nearest hit it knows.
+                typedef const __attribute__((address_space(4))) uint16_t* ConstIds;   // uniform reads through the scalar unit
+                ConstIds loose = (ConstIds)(uintptr_t)D.grid_loose;
+                for (int k = 0; k < D.grid_n_loose; ++k)
+                    if (active) exact(loose[k]);
+                GridWalk w = grid_begin(D, active, o, d);
+                int n = 0;
+                auto push = [&](uint32_t id) { list[n++] = (uint16_t)id; };   // two free places are kept
+                const float slack = (float)(2 * GRID_SLACK) * D.grid_h;
+                auto reach = [&]() -> float {
+                    if (!(best < __builtin_inf())) return w.t_out;
+                    return fminf(w.t_out, (float)((best - w.enter) * 1.000001) + slack);
+                };
+                float limit = reach();
+                for (int step = 1; __ballot(!w.done) != 0; ++step) {
+                    grid_step(D, w, limit, push);
+                    if (__ballot(n > GRID_LIST - 2) != 0 || ((step & (RT_GRID_CHECK - 1)) == 0 && __ballot(n > 0) != 0)) {
+                        for (int k = 0; __ballot(k < n) != 0; ++k)
+                            if (k < n) exact(list[k]);
+                        n = 0;
+                        limit = reach();
+                    }
+                }
+                for (int k = 0; __ballot(k < n) != 0; ++k)
+                    if (k < n) exact(list[k]);
+                every_sphere = false;
+            } else if (D.hier_top_groups) {
                 // Bounding-sphere hierarchy: a few dozen tests instead of one per sphere.  The ray
                 // is walked in windows that grow by a factor of 4: most rays of a scene full of
                 // spheres end close to where they start (inside a sphere, at a neighbour), and a

@@ -87,6 +87,17 @@ struct Dev {
     int32_t hier_blocks;           // the first hier_blocks entries of the top list are the blocks 0, 1, 2, ...
     float hier_window;             // length of the first stretch of a ray that k_trace searches (then x4, x16, ...)
     float hier_extent;             // from this length on a stretch is the whole rest of the ray
+    // uniform grid over the spheres (rt_grid.h), used instead of the hierarchy when grid_cells != 0
+    const uint32_t* grid_start;    // [grid_cells][2] first item and one past the last item of each cell
+    const uint16_t* grid_items;    // sphere indices, an even number per cell (padding: index S, the blank entry)
+    const float4* grid_sph;        // [S + 1] centre relative to grid_origin, radius + error term; entry S is blank
+    const uint16_t* grid_loose;    // spheres that are not in the grid: always tested
+    int32_t grid_n_loose;
+    int32_t grid_cells;
+    int32_t grid_n[3];             // cells along x, y, z
+    float grid_h, grid_inv_h;      // cell size
+    double grid_origin[3];         // the grid's box is [0, grid_hi] relative to this point
+    double grid_hi[3];
     // static tree
     const int32_t* node_a;
     const int32_t* node_b;

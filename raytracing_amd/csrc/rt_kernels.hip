@@ -45,12 +45,16 @@
 #ifndef RT_HIER_GROWTH
 #define RT_HIER_GROWTH 4    // each stretch of a ray searched in the sphere hierarchy is this many times the one before
 #endif
+#ifndef RT_GRID_CHECK
+#define RT_GRID_CHECK 4     // the candidates of a grid walk take the float64 test every this many steps (a power of two)
+#endif
 #ifndef RT_MIXED_WAVES
 #define RT_MIXED_WAVES 2   // waves per SIMD requested for the mixed-precision surface kernel
 #endif
 
 #include "rt_math.h"
 #include "rt_hier.h"
+#include "rt_grid.h"
 #include "rt_geometry.hip"
 #include "rt_samples.hip"
 #include "rt_lighting.hip"

@@ -70,7 +70,35 @@ __device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere
             }
         };
         bool every_sphere = true;   // this lane screens the whole table
-        if (D.hier_top_groups) {
+        if (D.grid_cells) {
+            // uniform grid: the spheres outside it and the survivors of the cells along the whole ray,
+            // then ascending sphere order (the order of the multiplications), every sphere once
+            const LaneList cand = lists.spheres;
+            typedef const __attribute__((address_space(4))) uint16_t* ConstIds;
+            ConstIds loose = (ConstIds)(uintptr_t)D.grid_loose;
+            int n = 0;
+            bool overflow = false;
+            auto push = [&](uint32_t id) {
+                // a sphere sits in every cell it reaches: the walk meets it in consecutive cells
+                if ((n > 0 && cand[n - 1] == id) || (n > 1 && cand[n - 2] == id)) return;
+                if (n < GRID_LIST) cand[n++] = (uint16_t)id; else overflow = true;
+            };
+            for (int k = 0; k < D.grid_n_loose; ++k) push(loose[k]);
+            GridWalk w = grid_begin(D, true, o, d);
+            while (__ballot(!w.done) != 0) grid_step(D, w, w.t_out, push);
+            for (int i = 1; i < n; ++i) {   // the list is short: insertion sort
+                const uint16_t v = cand[i];
+                int j = i;
+                while (j > 0 && cand[j - 1] > v) { cand[j] = cand[j - 1]; --j; }
+                cand[j] = v;
+            }
+            if (!overflow) {
+                for (int k = 0; __ballot(k < n) != 0; ++k)
+                    if (k < n && !opaque && (k == 0 || cand[k] != cand[k - 1])) occluder(cand[k]);
+            }
+            every_sphere = overflow;
+            if (overflow) { mult = {1, 1, 1}; opaque = false; }
+        } else if (D.hier_top_groups) {
             // the ray starts at -dot(ref - o, d) on the line, measured from `on`; rounded down
             const double s_o = -dot(ref - o, d);
             const float s_from = (float)(s_o - 1e-6 * fabs(s_o)) - e_ray;
