@@ -174,6 +174,10 @@ struct RtContext {
     DevBuf<uint32_t> grid_start;
     DevBuf<uint16_t> grid_items, grid_loose;
     DevBuf<float> grid_sph;
+    DevBuf<uint32_t> lmap_start;
+    DevBuf<uint16_t> lmap_items, lmap_always;
+    int lmap_start_off[RT_MAX_LIGHTS] = {0}, lmap_always_off[RT_MAX_LIGHTS] = {0}, lmap_n_always[RT_MAX_LIGHTS] = {0};
+    uint32_t lmap_mask = 0;
     int grid_cells = 0, grid_n_loose = 0, grid_n[3] = {0, 0, 0};
     float grid_h = 0, grid_inv_h = 0;
     double grid_origin[3] = {0, 0, 0}, grid_hi[3] = {0, 0, 0};
@@ -241,6 +245,8 @@ struct RtContext {
         D.grid_start = grid_start.p; D.grid_items = grid_items.p; D.grid_sph = reinterpret_cast<const float4*>(grid_sph.p); D.grid_loose = grid_loose.p;
         D.grid_n_loose = grid_n_loose; D.grid_cells = grid_cells; D.grid_h = grid_h; D.grid_inv_h = grid_inv_h;
         for (int k = 0; k < 3; ++k) { D.grid_n[k] = grid_n[k]; D.grid_origin[k] = grid_origin[k]; D.grid_hi[k] = grid_hi[k]; }
+        D.lmap_start = lmap_start.p; D.lmap_items = lmap_items.p; D.lmap_always = lmap_always.p; D.lmap_mask = lmap_mask;
+        for (int l = 0; l < RT_MAX_LIGHTS; ++l) { D.lmap_start_off[l] = lmap_start_off[l]; D.lmap_always_off[l] = lmap_always_off[l]; D.lmap_n_always[l] = lmap_n_always[l]; }
         D.node_a = node_a.p; D.node_b = node_b.p; D.node_branch = node_branch.p; D.node_child = node_child.p;
         D.level_start = level_start.p; D.K = tree.n_nodes(); D.n_levels = tree.n_levels();
         D.node_n = node_n.p; D.node_nglobal = user_batches ? user_batches : node_nglobal.p; D.nb = nb; D.node_nguess = batch_guess; D.batch_slot = batch_slot; D.batch_slots = batch_slots; D.node_hits = node_hits.p; D.node_beam = node_beam.p;
@@ -453,7 +459,7 @@ void rt_destroy(RtContext* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->collect();
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
-    ctx->geom.release(); ctx->mat.release(); ctx->fres.release(); ctx->cull.release(); ctx->hier_top.release(); ctx->hier_mid.release(); ctx->hier_leaf.release(); ctx->hier_top_ref.release(); ctx->hier_ids.release(); ctx->grid_start.release(); ctx->grid_items.release(); ctx->grid_loose.release(); ctx->grid_sph.release(); ctx->sc.release();
+    ctx->geom.release(); ctx->mat.release(); ctx->fres.release(); ctx->cull.release(); ctx->hier_top.release(); ctx->hier_mid.release(); ctx->hier_leaf.release(); ctx->hier_top_ref.release(); ctx->hier_ids.release(); ctx->grid_start.release(); ctx->grid_items.release(); ctx->grid_loose.release(); ctx->grid_sph.release(); ctx->lmap_start.release(); ctx->lmap_items.release(); ctx->lmap_always.release(); ctx->sc.release();
     ctx->node_a.release(); ctx->node_b.release(); ctx->node_branch.release(); ctx->node_child.release();
     ctx->level_start.release(); ctx->node_n.release(); ctx->node_nglobal.release(); ctx->node_hits.release();
     ctx->node_beam.release(); ctx->node_tile0.release(); ctx->node_ntiles.release(); ctx->lvl_ntiles.release();
@@ -578,6 +584,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
         // a bounding-sphere hierarchy.  RT_GRID_DENSITY: cells per sphere the grid aims at.
         ctx->hier_top_groups = 0;
         ctx->grid_cells = 0;
+        ctx->lmap_mask = 0;
         const char* use_hier = getenv("RT_HIERARCHY");
         const char* accel = getenv("RT_ACCEL");
         const bool accelerate = S > SPH_CHUNK_SMALL && !(use_hier && use_hier[0] == '0');
@@ -597,6 +604,28 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
                 ctx->grid_n_loose = (int)G.loose.size();
                 ctx->grid_h = G.h; ctx->grid_inv_h = G.inv_h;
                 for (int k = 0; k < 3; ++k) { ctx->grid_n[k] = G.n[k]; ctx->grid_origin[k] = G.origin[k]; ctx->grid_hi[k] = G.hi[k]; }
+                // point lights: their occluders by direction (RT_LIGHT_MAPS=0: shadow rays walk the grid)
+                const char* use_maps = getenv("RT_LIGHT_MAPS");
+                std::vector<char> in_grid(S, 1);
+                for (uint16_t i : G.loose) in_grid[i] = 0;
+                std::vector<uint32_t> all_start;
+                std::vector<uint16_t> all_items, all_always;
+                for (int l = 0; l < scene->n_lights && !(use_maps && use_maps[0] == '0'); ++l) {
+                    if (scene->lights[l].kind != RT_LIGHT_POINT) continue;
+                    const HostLightMap M = build_light_map(scene->sphere_geom, S, scene->lights[l].position, in_grid);
+                    if (!M.usable) continue;
+                    const uint32_t item_base = (uint32_t)all_items.size();
+                    ctx->lmap_start_off[l] = (int)all_start.size();
+                    ctx->lmap_always_off[l] = (int)all_always.size();
+                    ctx->lmap_n_always[l] = (int)M.always.size();
+                    for (uint32_t v : M.start) all_start.push_back(v + item_base);
+                    all_items.insert(all_items.end(), M.items.begin(), M.items.end());
+                    all_always.insert(all_always.end(), M.always.begin(), M.always.end());
+                    ctx->lmap_mask |= 1u << l;
+                }
+                HIP_TRY(upload(ctx->lmap_start, all_start));
+                HIP_TRY(upload(ctx->lmap_items, all_items));
+                HIP_TRY(upload(ctx->lmap_always, all_always));
             }
         }
         if (accelerate && ctx->grid_cells == 0) {

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(BLOCK) void k_debug(Dev D, int what, const double* 
                 break;
             }
             case RT_DEBUG_SHADOW: {         // reference objects.py:274-285
-                const V3 m = shadow_multiplier<true>(D, s_sh, no_lists, ld3(x), ld3(x + 3));
+                const V3 m = shadow_multiplier<true>(D, s_sh, no_lists, ld3(x), ld3(x + 3), -1);
                 y[0] = m.x; y[1] = m.y; y[2] = m.z;
                 break;
             }

@@ -98,6 +98,12 @@ struct Dev {
     float grid_h, grid_inv_h;      // cell size
     double grid_origin[3];         // the grid's box is [0, grid_hi] relative to this point
     double grid_hi[3];
+    // occluders of the point lights by direction (lightmap_build.h); bit l of lmap_mask: light l has a map
+    const uint32_t* lmap_start;    // per light [6 * LMAP_N * LMAP_N][2] item range of each bin, at lmap_start_off[l]
+    const uint16_t* lmap_items;    // sphere indices, ascending inside a bin
+    const uint16_t* lmap_always;   // per light the spheres tested for every ray, at lmap_always_off[l]
+    int32_t lmap_start_off[RT_MAX_LIGHTS], lmap_always_off[RT_MAX_LIGHTS], lmap_n_always[RT_MAX_LIGHTS];
+    uint32_t lmap_mask;
     // static tree
     const int32_t* node_a;
     const int32_t* node_b;

@@ -55,6 +55,7 @@
 #include "rt_math.h"
 #include "rt_hier.h"
 #include "rt_grid.h"
+#include "lightmap_build.h"
 #include "rt_geometry.hip"
 #include "rt_samples.hip"
 #include "rt_lighting.hip"

@@ -39,8 +39,9 @@ __device__ __forceinline__ double pow_shininess(double x, double sh) {
 struct ShadowLists {   // per-lane lists in LDS for the screening of many spheres (rt_hier.h)
     LaneList clusters, spheres;
 };
+// `light`: index of the point light the ray goes to, or -1 (a sample of a disk light).
 template <bool LDS>
-__device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere* s_sh, const ShadowLists& lists, V3 o, V3 d) {
+__device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere* s_sh, const ShadowLists& lists, V3 o, V3 d, int light) {
     V3 mult = {1, 1, 1};
     const int S = D.S;
     const double d_o = dot(d, o);
@@ -83,9 +84,60 @@ __device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere
                 if ((n > 0 && cand[n - 1] == id) || (n > 1 && cand[n - 2] == id)) return;
                 if (n < GRID_LIST) cand[n++] = (uint16_t)id; else overflow = true;
             };
-            for (int k = 0; k < D.grid_n_loose; ++k) push(loose[k]);
-            GridWalk w = grid_begin(D, true, o, d);
-            while (__ballot(!w.done) != 0) grid_step(D, w, w.t_out, push);
+            bool walk = true;
+            if (light >= 0 && ((D.lmap_mask >> light) & 1u)) {
+                // A point light with a map of its occluders by direction (lightmap_build.h): the ray lies on
+                // a line through the light, so what it can touch is listed in the bin of the direction
+                // from the light to the ray's origin and in the bin of the opposite direction, plus the
+                // light's "always" spheres.  The listed spheres take the float32 screening of the grid.
+                ConstIds always = (ConstIds)(uintptr_t)(D.lmap_always + D.lmap_always_off[light]);
+                for (int k = 0; k < D.lmap_n_always[light]; ++k) push(always[k]);
+                const double* lp = D.sc->lights[light].position;
+                const float qx = (float)(o.x - lp[0]), qy = (float)(o.y - lp[1]), qz = (float)(o.z - lp[2]);
+                const float ax = fabsf(qx), ay = fabsf(qy), az = fabsf(qz);
+                int face;
+                float qa, qb, qc;
+                if (ax >= ay && ax >= az) { face = 0; qa = qx; qb = qy; qc = qz; }
+                else if (ay >= az) { face = 2; qa = qy; qb = qz; qc = qx; }
+                else { face = 4; qa = qz; qb = qx; qc = qy; }
+                if (qa < 0) face |= 1;
+                if (!(fabsf(qa) > 1e-20f)) overflow = true;   // the ray starts at the light itself: no direction, walk the grid
+                const float inv = 1.0f / fabsf(qa);
+                const float u = qb * inv, w_ = qc * inv;
+                // the ray in the grid's coordinates, as the screening entries are
+                const float px = (float)(o.x - D.grid_origin[0]), py = (float)(o.y - D.grid_origin[1]), pz = (float)(o.z - D.grid_origin[2]);
+                const float fx = (float)d.x, fy = (float)d.y, fz = (float)d.z;
+                const float e_ray = 1.5e-6f * ((fabsf(px) + fabsf(py) + fabsf(pz)) * 1.000001f);
+                const uint32_t* start = D.lmap_start + D.lmap_start_off[light];
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const float su = side ? -u : u, sw = side ? -w_ : w_;
+                    const int iu = min(max((int)floorf((su * 0.5f + 0.5f) * LMAP_N), 0), LMAP_N - 1);
+                    const int iw = min(max((int)floorf((sw * 0.5f + 0.5f) * LMAP_N), 0), LMAP_N - 1);
+                    const uint32_t bin = ((uint32_t)(face ^ side) * LMAP_N + iw) * LMAP_N + iu;
+                    const uint2 se = *reinterpret_cast<const uint2*>(start + 2 * (size_t)bin);
+                    for (uint32_t k = se.x; __ballot(k < se.y) != 0; ++k) {
+                        if (k < se.y) {
+                            const uint32_t id = D.lmap_items[k];
+                            const float4 s = D.grid_sph[id];
+                            const float ocx = s.x - px, ocy = s.y - py, ocz = s.z - pz;
+                            const float b = fmaf(ocz, fz, fmaf(ocy, fy, ocx * fx));
+                            const float rx = fmaf(-b, fx, ocx), ry = fmaf(-b, fy, ocy), rz = fmaf(-b, fz, ocz);
+                            const float p2 = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
+                            const float t = s.w + e_ray;
+                            // not a certain miss of the line, and not wholly behind the ray's origin
+                            if (!(fmaf(-t, t, p2) > 0) && !(-(b + t) > 0)) push(id);
+                        }
+                    }
+                }
+                walk = overflow;
+                if (overflow) { n = 0; overflow = false; }
+            }
+            if (walk) {
+                for (int k = 0; k < D.grid_n_loose; ++k) push(loose[k]);
+                GridWalk w = grid_begin(D, true, o, d);
+                while (__ballot(!w.done) != 0) grid_step(D, w, w.t_out, push);
+            }
             for (int i = 1; i < n; ++i) {   // the list is short: insertion sort
                 const uint16_t v = cand[i];
                 int j = i;
@@ -206,7 +258,7 @@ __device__ SampleTerms disk_sample_f64(const Dev& D, const ShadowSphere* s_sh, c
     V3 Lv = lp - Pb;
     const double dist = sqrt(dot(Lv, Lv));
     V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
-    V3 mult = shadow_multiplier<LDS>(D, s_sh, cand, Pb, Lh);
+    V3 mult = shadow_multiplier<LDS>(D, s_sh, cand, Pb, Lh, -1);
     const double fall = (Lt.intensity / Lt.n_points) / (dist * dist);
     SampleTerms o;
     o.Id = clip01((fall * ld3(Lt.diffuse_color)) * mult);
@@ -238,7 +290,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
             const double d2 = dot(Lv, Lv);
             const double dist = sqrt(d2);
             V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
-            V3 mult = shadow_multiplier<LDS>(D, s_sh, cand, Pb, Lh);
+            V3 mult = shadow_multiplier<LDS>(D, s_sh, cand, Pb, Lh, l);
             const double fall = Lt.intensity / (dist * dist);
             V3 Id = clip01((fall * dcol) * mult), Is = clip01((fall * scol) * mult);
             const double nl = dot(n, Lh);

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIXED_WAVES) void k_surface_mixed(Dev D) 
             const V3 Lv = lpos - Pb;
             const double dist = sqrt(dot(Lv, Lv));
             const V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
-            const V3 mult = shadow_multiplier<true>(D, s_sh, no_lists, Pb, Lh);
+            const V3 mult = shadow_multiplier<true>(D, s_sh, no_lists, Pb, Lh, -1);
             const double fall = sc->lights[l].intensity / (dist * dist);
             const V3 Id = clip01((fall * dcol) * mult), Is = clip01((fall * scol) * mult);
             const double nl = dot(n, Lh);
