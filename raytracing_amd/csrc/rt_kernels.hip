@@ -40,7 +40,7 @@
 #define RT_SURFACE_WAVES 2   // waves per SIMD requested for the float64 lighting kernel (few spheres)
 #endif
 #ifndef RT_SURFACE_WAVES_MANY
-#define RT_SURFACE_WAVES_MANY 4   // waves per SIMD requested for the many-sphere variant of k_surface (measured: 2: 42.9 ms, 4: 40.2, 6: 44.3 for 4096 spheres at 4K)
+#define RT_SURFACE_WAVES_MANY 3   // waves per SIMD requested for the many-sphere variant of k_surface (measured with the grid and the light maps, 4096 spheres at 4K: 2: 24.7 ms, 3: 24.6, 4: 27.0, 6: 41.8, 8: 54.6)
 #endif
 #ifndef RT_HIER_GROWTH
 #define RT_HIER_GROWTH 4    // each stretch of a ray searched in the sphere hierarchy is this many times the one before
