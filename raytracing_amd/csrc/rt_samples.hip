@@ -194,6 +194,300 @@ __global__ __launch_bounds__(256) void k_mt_generate(uint32_t* rings, long long*
     if (tid == 0) gen_ends[t] = g0 + (long long)iters * 2 * MT_STEP;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generated values straight into the packed layout (disk lights): k_mt_emit is k_mt_generate that
+// keeps its words in LDS and, every few steps, turns the new ones into doubles and stores each at the
+// place of the (hit, sample) it belongs to - the raw words never reach device memory, and values of
+// hits that are not shaded (two thirds of the stream in the example scenes) are dropped on the spot.
+//
+// Where a value belongs follows from its position p in the stream: the (node, light) block that
+// holds p (EmitBlock, sorted by offset), there part (angles, then radii), sample s and column j -
+// the j-th hit of the node in pixel order.  Whether that hit is on the shading list, and at which
+// entry, is answered by one bit per hit (k_hitmask: bit j of the node's range is set for a shaded
+// hit) and a running count per 64 bits (k_hitprefix): entries of a node are consecutive, in hit order.
+struct EmitBlock {
+    int64_t off, end;          // positions [off, end) of the stream: 2 * n_points rows of h values
+    double inv_h;              // 1 / h
+    uint32_t h;                // values per row (the node's hits in the whole image)
+    uint32_t rows;             // n_points (the radius rows follow the angle rows)
+    uint32_t first_col, mine;  // this context's hits are the columns [first_col, first_col + mine)
+    uint32_t word0;            // first 64-bit word of the node's range in the hit mask
+    uint32_t e_first;          // shading-list entry of the node's first shaded hit
+    uint32_t light;
+    uint32_t pad;
+};
+static_assert(sizeof(EmitBlock) == 56, "EmitBlock is read as seven 8-byte words");
+
+// One bit per hit, in node order then pixel order: set if the hit is on the shading list.  One launch
+// per level, the grid and the tile runs of k_link.  mask must be zero on entry.
+__global__ __launch_bounds__(BLOCK) void k_hitmask(Dev D, int level, const uint32_t* __restrict__ node_word0, unsigned long long* mask) {
+    extern __shared__ int s_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (D.flags[0]) return;
+    const int k0 = D.level_start[level], nn = D.level_start[level + 1] - k0;
+    const int nt = D.lvl_ntiles[level];
+    const int tbase = D.lvl_tilebase[level];
+    const int q = tiles_per_wave(D, nt);
+    const int wid = blockIdx.x * WPB + wave;
+    const int t_begin = wid * q;
+    const int t_end = min(nt, t_begin + q);
+    if (blockIdx.x * WPB * q >= nt) return;
+    const LevelTables T = stage_level_tables(D, level, s_dyn, tid, blockIdx.x * WPB * q, min(nt, (int)(blockIdx.x + 1) * WPB * q) - 1);
+    const unsigned wave_base = D.blk_tot[((size_t)level * NCNT + C_HIT) * NB + blockIdx.x] + D.wave_off[((size_t)level * NCNT + C_HIT) * NW + wid];
+    __syncthreads();
+    int kk = (t_begin < t_end) ? find_node(T.node, nn, t_begin) : 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        while (T.node[kk].tile_end <= t) ++kk;
+        kk = __builtin_amdgcn_readfirstlane(kk);
+        const NodeRec r = T.node[kk];
+        const int first = (t - __builtin_amdgcn_readfirstlane(r.tile0)) * TILE;
+        const int cnt = min(TILE, __builtin_amdgcn_readfirstlane(r.n) - first);
+        const uint32_t info = lane < cnt ? D.info[(uint32_t)(tbase + t) * TILE + lane] : I_NO_HIT;
+        const unsigned long long hits = __ballot(is_hit(info));
+        if (hits == 0) continue;
+        const unsigned trun = D.tile_run[(size_t)(tbase + t) * NCNT + C_HIT];
+        // shade bits in hit order: hit number i of the tile sends its bit to lane i
+        const int nh = __popcll(hits);
+        const int dest = is_hit(info) ? lanes_below(hits) : 63;
+        const int got = __builtin_amdgcn_ds_permute(dest * 4, (info & I_SHADE) ? 1 : 0);
+        unsigned long long bits = __ballot(got != 0);
+        if (nh < 64) bits &= (1ull << nh) - 1;
+        // rank of the tile's first hit inside its node -> place in the mask
+        const unsigned long long place = (unsigned long long)node_word0[k0 + kk] * 64 + (wave_base + trun - T.pre[kk * 16 + C_HIT]);
+        const unsigned sh = (unsigned)(place & 63);
+        if (lane == 0 && bits != 0) {
+            atomicOr(&mask[place >> 6], bits << sh);
+            if (sh != 0 && (bits >> (64 - sh)) != 0) atomicOr(&mask[(place >> 6) + 1], bits >> (64 - sh));
+        }
+    }
+}
+
+// Set bits before each word of a node's range of the hit mask.  One workgroup per node.
+__global__ __launch_bounds__(BLOCK) void k_hitprefix(const unsigned long long* __restrict__ mask, const uint32_t* __restrict__ node_word0, uint32_t* __restrict__ pref) {
+    __shared__ unsigned s_wave[WPB];
+    __shared__ unsigned s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t w0 = node_word0[blockIdx.x], w1 = node_word0[blockIdx.x + 1];
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = w0; base < w1; base += BLOCK) {
+        const uint32_t w = base + tid;
+        const unsigned c = w < w1 ? (unsigned)__popcll(mask[w]) : 0u;
+        unsigned incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned before = s_carry;
+        for (int v = 0; v < wave; ++v) before += s_wave[v];
+        if (w < w1) pref[w] = before + incl - c;
+        __syncthreads();
+        if (tid == BLOCK - 1) s_carry = before + incl;
+        __syncthreads();
+    }
+}
+
+// grid: one workgroup per stream t = blockIdx.x (see k_mt_generate for rings, gen_ends, ell, last_stream,
+// gen_until).  Value v of the stream (0 <= v < n_values) is built from the words pos + 2 v and pos + 2 v + 1
+// (words below w_end exist) and goes to the packed layout if its hit is shaded.
+constexpr int EMIT_RING = 8192;          // words kept in LDS
+#ifndef RT_EMIT_STEPS
+#define RT_EMIT_STEPS 14
+#endif
+constexpr int EMIT_STEPS = RT_EMIT_STEPS;   // double steps (454 words each) between two rounds of stores
+#ifndef RT_EMIT_GROUP
+#define RT_EMIT_GROUP 4
+#endif
+constexpr int EMIT_GROUP = RT_EMIT_GROUP;   // batches of 64 values whose loads a wave has in flight together
+static_assert(EMIT_STEPS * 2 * MT_STEP + MT_N + 8 + 2 * 64 < EMIT_RING, "a round's words and the recurrence's reach fit the ring");
+__global__ __launch_bounds__(256) void k_mt_emit(Dev D, uint32_t* rings, long long* gen_ends, int ell, long long pos, long long n_values, long long w_end,
+                                                 int last_stream, long long gen_until, const EmitBlock* __restrict__ blocks, int n_blocks,
+                                                 const unsigned long long* __restrict__ mask, const uint32_t* __restrict__ pref) {
+    __shared__ uint32_t ring[EMIT_RING];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = blockIdx.x;
+    uint32_t* ring_g = rings + (size_t)t * MT_RING;
+    const long long g0 = gen_ends[t];
+    for (int i = tid; i < MT_RING; i += 256) {
+        // ring_g[n & 2047] holds x[n] for the 2048 indices below g0
+        const long long n = g0 - MT_RING + i;
+        ring[n & (EMIT_RING - 1)] = ring_g[n & (MT_RING - 1)];
+    }
+    const long long raw_first = ((long long)t << ell) + (t > 0 ? 1 : 0);
+    long long raw_end = ((long long)(t + 1) << ell) + 2;
+    if (raw_end > w_end) raw_end = w_end;
+    if (raw_end < raw_first) raw_end = raw_first;
+    long long target = raw_end > g0 ? raw_end : g0;
+    if (t == last_stream && gen_until > target) target = gen_until;
+    // values whose two words both lie in [raw_first, raw_end)
+    long long v_next = raw_first <= pos ? 0 : (raw_first - pos + 1) >> 1;
+    long long v_stop = raw_end - 2 - pos >= 0 ? ((raw_end - 2 - pos) >> 1) + 1 : 0;
+    if (v_stop > n_values) v_stop = n_values;
+    __syncthreads();
+
+    const bool lane_on = tid < MT_STEP;
+    long long g = g0;   // words below g exist
+    uint32_t prev = lane_on ? ring[(g + tid - MT_STEP) & (EMIT_RING - 1)] : 0u;
+    if (n_blocks < 0) n_blocks = 0;   // (measurement: generate only)
+    EmitBlock cur = blocks[0];   // the block the wave's last batch began in
+    struct {
+        long long v0, v1;      // stream positions [v0, v1) of the row the wave's last batch began in (one sample of one part of a block)
+        int64_t at;            // index in D.packed of the row's entry 0
+        uint32_t first_col, mine, word0, e_first;
+    } row = {0, 0, 0, 0, 0, 0, 0};
+    struct { long long v0, v1; } gap = {0, 0};   // a range of positions without a block
+    while (true) {
+        // ---- generate: up to EMIT_STEPS double steps (all four twist operands were written before the previous barrier)
+        for (int it = 0; it < EMIT_STEPS && g < target; ++it) {
+            if (lane_on) {
+                const int s0 = (int)((g + tid) & (EMIT_RING - 1)), s1 = (s0 + MT_STEP) & (EMIT_RING - 1);
+                const uint32_t lo0 = ring[(s0 - MT_N) & (EMIT_RING - 1)], hi0 = ring[(s0 - MT_N + 1) & (EMIT_RING - 1)];
+                const uint32_t lo1 = ring[(s1 - MT_N) & (EMIT_RING - 1)], hi1 = ring[(s1 - MT_N + 1) & (EMIT_RING - 1)];
+                const uint32_t x0 = prev ^ mt_twist(lo0, hi0);
+                const uint32_t x1 = x0 ^ mt_twist(lo1, hi1);
+                ring[s0] = x0;
+                ring[s1] = x1;
+                prev = x1;
+            }
+            g += 2 * MT_STEP;
+            __syncthreads();
+        }
+        // ---- store: the values whose words exist now, 64 consecutive ones per wave and batch (whole
+        // batches only until the stream's end, so that a batch is always the same 64 positions).  Nearly
+        // always the 64 positions lie in one row of one block: block, part, sample and first column are
+        // then found once for the batch (the same arithmetic in every lane), and a lane adds its number
+        // to the column.  The loads of EMIT_GROUP batches (mask word, count) are requested before the
+        // first of them is used.
+        const bool final_round = g >= target;
+        long long v_avail = g - 2 - pos >= 0 ? ((g - 2 - pos) >> 1) + 1 : 0;
+        if (v_avail > v_stop) v_avail = v_stop;
+        const long long b_stop = final_round ? (v_stop + 63) >> 6 : v_avail >> 6;
+        const long long v_to = final_round ? v_stop : (b_stop << 6);
+        for (long long b0 = (v_next >> 6) + wave; b0 < b_stop && n_blocks > 0; b0 += (long long)EMIT_GROUP * 4) {
+            struct Slot {
+                double u;
+                int64_t at;        // index in D.packed of entry 0 of the value's row
+                uint32_t word;     // word of the hit mask with the hit's bit
+                uint32_t bit, e_first;
+                bool ok;
+            } slot[EMIT_GROUP];
+            unsigned long long m[EMIT_GROUP];
+            uint32_t before[EMIT_GROUP];
+#pragma unroll
+            for (int k = 0; k < EMIT_GROUP; ++k) {
+                Slot& S = slot[k];
+                S.ok = false; S.u = 0; S.at = 0; S.word = 0; S.bit = 0; S.e_first = 0;
+                const long long vb = (b0 + 4 * k) << 6;
+                if (b0 + 4 * k >= b_stop) continue;   // uniform
+                // lanes of a partial batch (the stream's first and last one) that have no value
+                const int lane_lo = vb < v_next ? (int)(v_next - vb) : 0, lane_hi = vb + 64 > v_to ? (int)(v_to - vb) : 64;
+                uint32_t col;
+                if (vb >= gap.v0 && vb + 63 < gap.v1) continue;   // between two blocks: values of nodes without a shaded hit
+                if (vb >= row.v0 && vb + 63 < row.v1) {
+                    // the usual case: all 64 positions in the row of the batch before
+                    col = (uint32_t)(vb - row.v0) + lane;
+                } else {
+                    // the batch's first position: block, part, sample, column (uniform)
+                    if (!(vb >= cur.off && vb < cur.end)) {   // (kept in registers: a stream lies in a handful of blocks)
+                        int a = 0, z = n_blocks - 1;
+                        while (a < z) {
+                            const int mid = (a + z) >> 1;
+                            if (blocks[mid].end > vb) z = mid; else a = mid + 1;
+                        }
+                        cur = blocks[a];
+                        if (vb < cur.off) {
+                            // positions below this block that no block holds (the caller lists only nodes with shaded hits)
+                            gap.v0 = a > 0 ? blocks[a - 1].end : 0;
+                            gap.v1 = cur.off;
+                            if (vb >= gap.v0 && vb + 63 < gap.v1) continue;
+                        }
+                    }
+                    EmitBlock B = cur;
+                    long long v = vb + lane;
+                    unsigned long long r = (unsigned long long)(vb - B.off);
+                    const unsigned long long half = (unsigned long long)B.rows * B.h;
+                    int part = (vb >= B.off && r >= half) ? 1 : 0;
+                    if (part) r -= half;
+                    unsigned long long smp = (unsigned long long)((double)r * B.inv_h);
+                    if (smp * B.h > r) --smp;
+                    unsigned long long c0 = r - smp * B.h;
+                    if (c0 >= B.h) { ++smp; c0 -= B.h; }
+                    if (vb >= B.off && vb < B.end) {
+                        // the row the batch begins in is the wave's row from now on
+                        row.v0 = vb - (long long)c0;
+                        row.v1 = row.v0 + B.h;
+                        row.at = D.pack_base[B.light] + (int64_t)part * D.pack_plane + (int64_t)smp * D.pack_E;
+                        row.first_col = B.first_col; row.mine = B.mine; row.word0 = B.word0; row.e_first = B.e_first;
+                    }
+                    if (vb >= row.v0 && vb + 63 < row.v1) {
+                        col = (uint32_t)c0 + lane;
+                    } else {
+                        // a batch across the end of a row (or of a block): every lane finds its own place
+                        int a = 0, z = n_blocks - 1;
+                        while (a < z) {
+                            const int mid = (a + z) >> 1;
+                            if (blocks[mid].end > v) z = mid; else a = mid + 1;
+                        }
+                        B = blocks[a];
+                        if (!(v >= B.off && v < B.end) || lane < lane_lo || lane >= lane_hi) continue;
+                        r = (unsigned long long)(v - B.off);
+                        const unsigned long long half_ = (unsigned long long)B.rows * B.h;
+                        part = r >= half_ ? 1 : 0;
+                        if (part) r -= half_;
+                        smp = (unsigned long long)((double)r * B.inv_h);
+                        if (smp * B.h > r) --smp;
+                        c0 = r - smp * B.h;
+                        if (c0 >= B.h) { ++smp; c0 -= B.h; }
+                        if (c0 < B.first_col || c0 - B.first_col >= B.mine) continue;   // another context's column
+                        const uint32_t jl = (uint32_t)(c0 - B.first_col);
+                        const uint32_t w0 = (uint32_t)(pos + 2 * v);
+                        const uint32_t hi = mt_temper(ring[w0 & (EMIT_RING - 1)]) >> 5, lo = mt_temper(ring[(w0 + 1) & (EMIT_RING - 1)]) >> 6;
+                        S.u = ((double)hi * 67108864.0 + (double)lo) * 1.1102230246251565e-16;
+                        S.at = D.pack_base[B.light] + (int64_t)part * D.pack_plane + (int64_t)smp * D.pack_E;
+                        S.word = B.word0 + (jl >> 6);
+                        S.bit = jl & 63;
+                        S.e_first = B.e_first;
+                        S.ok = true;
+                        continue;
+                    }
+                }
+                const uint32_t jl = col - row.first_col;
+                if (!(jl < row.mine) || col < row.first_col || lane < lane_lo || lane >= lane_hi) continue;   // another context's column
+                const uint32_t w0 = (uint32_t)(pos + 2 * vb) + 2 * lane;
+                const uint32_t hi = mt_temper(ring[w0 & (EMIT_RING - 1)]) >> 5, lo = mt_temper(ring[(w0 + 1) & (EMIT_RING - 1)]) >> 6;
+                S.u = ((double)hi * 67108864.0 + (double)lo) * 1.1102230246251565e-16;   // 2^-53, exact
+                S.at = row.at;
+                S.word = row.word0 + (jl >> 6);
+                S.bit = jl & 63;
+                S.e_first = row.e_first;
+                S.ok = true;
+            }
+#pragma unroll
+            for (int k = 0; k < EMIT_GROUP; ++k) {
+                m[k] = slot[k].ok ? mask[slot[k].word] : 0ull;
+                before[k] = slot[k].ok ? pref[slot[k].word] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < EMIT_GROUP; ++k) {
+                const Slot& S = slot[k];
+                if (S.ok && ((m[k] >> S.bit) & 1ull))   // a hit that is not shaded: nobody reads its samples
+                    D.packed[S.at + (int64_t)(S.e_first + before[k] + (uint32_t)__popcll(m[k] & ((1ull << S.bit) - 1)))] = S.u;
+            }
+        }
+        if (v_to > v_next) v_next = v_to;
+        __syncthreads();   // the next round overwrites ring slots this round read
+        if (g >= target) break;
+    }
+    // the last 2048 words, where k_mt_generate keeps them
+    for (int i = tid; i < MT_RING; i += 256) {
+        const long long n = g - MT_RING + i;
+        ring_g[n & (MT_RING - 1)] = ring[n & (EMIT_RING - 1)];
+    }
+    if (tid == 0) gen_ends[t] = g;
+}
+
 // Jump-ahead.  Workgroup blockIdx.x makes the start window of stream t = blockIdx.x + 1:
 // the window at word index t L, reached from the caller's key block (the window at index 0, in
 // ring 0, which must not have generated yet) by applying, for every set bit b of t, the
