@@ -272,12 +272,40 @@ int rt_upload_samples_noalloc(RtContext *ctx, int64_t dst_offset, const double *
  * among them (rt_set_sample_layout_global, after rt_set_sample_layout; `total` = length of
  * the whole stream).  Every context then generates the whole stream and keeps its columns,
  * and all of them return the same final state.  The generator's work buffer (8 bytes per value of
- * the stream) stays with the context between calls while it is at most 64 GB; longer streams are
- * made in several passes through a buffer that is released again. */
+ * the stream) stays with the context between calls while it is at most 64 GB (RT_MT_RAW_KEEP_GB
+ * in the environment; rt_trim releases it at once); longer streams, or ones that half of the free
+ * device memory does not hold, are made in several passes through a buffer that is released again.
+ * RT_MT_FUSED=1 (disk lights only): the values go straight to their places, no such buffer at all,
+ * at about 1.6 times the kernel time. */
 int rt_set_sample_layout_global(RtContext *ctx, const int64_t *offsets, const int64_t *columns,
                                 const int64_t *first_column /* each [n_nodes][RT_MAX_LIGHTS] */, int64_t total);
 int rt_generate_samples(RtContext *ctx, const uint32_t *key /* [624] */, int32_t pos,
                         uint32_t *key_out /* [624] */, int32_t *pos_out);
+
+/* Host only (checks without a GPU): what rt_set_scene builds over a scene with more than 64 spheres
+ * (the reference loops over all spheres for every ray, objects.py:288-299 and :274-285; these
+ * structures only narrow down which spheres can matter, the float64 test of the reference decides).
+ * rt_build_grid: the uniform grid.  dims[3] cells per axis (0: no grid), origin_cell[4] = the box's
+ * lower corner and the cell size, the spheres kept out of the grid (always tested), and per cell
+ * the spheres whose ball, enlarged by the registration slack, reaches it: cell_first[cells + 1],
+ * items[*n_items], cell index = (z * dims[1] + y) * dims[0] + x.  Output pointers may be NULL (call
+ * once for the sizes).  density: cells per sphere aimed at (<= 0: the default, 2).
+ * rt_build_light_map: occluders of a point light at light[3] by direction as seen from the light,
+ * 6 * N * N bins (face = largest component of the direction: +x, -x, +y, -y, +z, -z; bin =
+ * (face * N + iw) * N + iu with u, w the next two components divided by the largest, mapped from
+ * [-1, 1] to [0, N)); in_grid[n] (NULL: all) tells which spheres have a screening entry, the others
+ * and those that contain the light or reach very many bins are listed in always[]
+ * (*n_always = -1: too many, such a light gets no map). */
+int rt_build_grid(const double *sphere_geom /* [n][4] */, int64_t n, double density, int32_t *dims, double *origin_cell,
+                  int32_t *n_loose, int32_t *loose /* [n] */, int64_t *n_items, int32_t *cell_first, int32_t *items);
+int rt_build_light_map(const double *sphere_geom /* [n][4] */, int64_t n, const double *light, const uint8_t *in_grid,
+                       int32_t *bins_per_edge, int32_t *n_always, int32_t *always /* [n] */, int64_t *n_items,
+                       int32_t *bin_first /* [6 N N + 1] */, int32_t *items);
+
+/* Gives back the work buffers of the sample calls (the generator's raw words and stream states, the
+ * staging buffer of rt_upload_samples): they are allocated again when next needed.  No counterpart in
+ * the reference.  Waits for the context's stream. */
+int rt_trim(RtContext *ctx);
 
 /* Host only: the coefficients (bit i = coefficient of x^i, 624 words) of x^(2^k) mod the
  * characteristic polynomial of MT19937's one-word step - the jump-ahead polynomials
@@ -301,7 +329,9 @@ int rt_set_precision(RtContext *ctx, int32_t mode);
  * raytrace.py:135-170 and objects.py:94-235), deepest level first.  Leaves the
  * clipped pixel colours (reference raytrace.py:15) on the device.  Does not
  * synchronise.  With disk lights in the scene: RT_ERR_STATE unless the whole sample stream
- * announced by rt_set_sample_layout has been uploaded or generated. */
+ * announced by rt_set_sample_layout has been uploaded or generated.  The first call after new
+ * samples also converts them for the float32 pass and must not be made under stream capture
+ * (RT_ERR_STATE); later calls can be captured into a HIP graph. */
 int rt_shade(RtContext *ctx);
 
 /* Optional: have rt_shade write the colours into caller-owned DEVICE memory

@@ -98,6 +98,9 @@ SIGNATURES = {
     "rt_build_hierarchy": (C.c_int, [_F64P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint16),
                                      C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "rt_mt19937_jump_poly": (C.c_int, [C.c_int32, C.POINTER(C.c_uint32)]),
+    "rt_build_grid": (C.c_int, [_F64P, C.c_int64, C.c_double, _I32P, _F64P, _I32P, _I32P, _I64P, _I32P, _I32P]),
+    "rt_build_light_map": (C.c_int, [_F64P, C.c_int64, _F64P, C.POINTER(C.c_uint8), _I32P, _I32P, _I32P, _I64P, _I32P, _I32P]),
+    "rt_trim": (C.c_int, [_P]),
     "rt_set_sample_layout_global": (C.c_int, [_P, _I64P, _I64P, _I64P, C.c_int64]),
     "rt_generate_samples": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "rt_set_precision": (C.c_int, [_P, C.c_int32]),
@@ -398,19 +401,36 @@ class Context:
         weakref.finalize(buf, self.lib.rt_free_host, _P(p.value))
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
-    def read_image(self):
-        out = self._host_array((self.npix, 3), np.float64)
+    def alloc_host(self, shape, dtype=np.float64):
+        """Page-locked NumPy array (rt_alloc_host; freed when the array is collected) to pass as ``out=``
+        of read_image / read_image_rgb8: the copy into it is one transfer at the link's rate.  Meant to
+        be allocated once and reused; pinning and unpinning memory per frame is slow."""
+        return self._host_array(shape, dtype)
+
+    def read_image(self, out=None):
+        """The frame as an (npix, 3) float64 array: an ordinary NumPy array, or ``out`` (see alloc_host)."""
+        if out is None:
+            out = np.empty((self.npix, 3), dtype=np.float64)
+        if out.dtype != np.float64 or out.size != self.npix * 3 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of npix * 3 values")
         _check(self.lib.rt_read_image(self._h, _ptr(out, C.c_double)))
-        return out
+        return out.reshape(self.npix, 3)
 
     def quantise_rgb8(self, device_ptr=None):
         """8-bit image into caller-owned device memory (None: the context's buffer); no synchronisation."""
         _check(self.lib.rt_quantise_rgb8(self._h, _P(device_ptr) if device_ptr else None))
 
-    def read_image_rgb8(self):
-        out = self._host_array((self.npix, 3), np.uint8)
+    def read_image_rgb8(self, out=None):
+        if out is None:
+            out = np.empty((self.npix, 3), dtype=np.uint8)
+        if out.dtype != np.uint8 or out.size != self.npix * 3 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of npix * 3 values")
         _check(self.lib.rt_read_image_rgb8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
-        return out
+        return out.reshape(self.npix, 3)
+
+    def trim(self):
+        """Give the work buffers of the sample calls back (rt_trim)."""
+        _check(self.lib.rt_trim(self._h))
 
     def image_device_ptr(self):
         p = _P()

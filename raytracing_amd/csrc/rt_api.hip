@@ -431,6 +431,54 @@ int rt_build_hierarchy(const double* sphere_geom, int64_t n, int32_t* n_blocks, 
     return RT_OK;
 }
 
+int rt_build_grid(const double* sphere_geom, int64_t n, double density, int32_t* dims, double* origin_cell, int32_t* n_loose,
+                  int32_t* loose, int64_t* n_items, int32_t* cell_first, int32_t* items) {
+    if (n < 0 || n >= 0xFFFF || (n > 0 && !sphere_geom)) return fail(RT_ERR_INVALID, "sphere_geom must hold 0 <= n < 65535 spheres");
+    const HostGrid G = build_grid(sphere_geom, (size_t)n, density > 0 ? density : 2.0);
+    const size_t cells = G.start.empty() ? 0 : (size_t)G.cells();
+    if (dims) for (int k = 0; k < 3; ++k) dims[k] = cells ? G.n[k] : 0;
+    if (origin_cell) { for (int k = 0; k < 3; ++k) origin_cell[k] = G.origin[k]; origin_cell[3] = G.h; }
+    if (n_loose) *n_loose = (int32_t)G.loose.size();
+    if (loose) for (size_t i = 0; i < G.loose.size(); ++i) loose[i] = G.loose[i];
+    // the lists without their padding
+    int64_t total = 0;
+    for (size_t c = 0; c < cells; ++c) {
+        if (cell_first) cell_first[c] = (int32_t)total;
+        for (uint32_t k = G.start[2 * c]; k < G.start[2 * c + 1]; ++k)
+            if (G.items[k] != (uint16_t)n) {
+                if (items) items[total] = G.items[k];
+                ++total;
+            }
+    }
+    if (cell_first) cell_first[cells] = (int32_t)total;
+    if (n_items) *n_items = total;
+    return RT_OK;
+}
+
+int rt_build_light_map(const double* sphere_geom, int64_t n, const double* light, const uint8_t* in_grid, int32_t* bins_per_edge,
+                       int32_t* n_always, int32_t* always, int64_t* n_items, int32_t* bin_first, int32_t* items) {
+    if (n < 0 || n >= 0xFFFF || (n > 0 && !sphere_geom) || !light) return fail(RT_ERR_INVALID, "bad arguments");
+    std::vector<char> flags((size_t)n, 1);
+    if (in_grid) for (int64_t i = 0; i < n; ++i) flags[i] = in_grid[i] ? 1 : 0;
+    const HostLightMap M = build_light_map(sphere_geom, (size_t)n, light, flags);
+    if (bins_per_edge) *bins_per_edge = LMAP_N;
+    if (n_always) *n_always = M.usable ? (int32_t)M.always.size() : -1;   // -1: too many, no map is used for this light
+    if (always && M.usable) for (size_t i = 0; i < M.always.size(); ++i) always[i] = M.always[i];
+    const size_t bins = (size_t)6 * LMAP_N * LMAP_N;
+    int64_t total = 0;
+    if (M.usable)
+        for (size_t b = 0; b < bins; ++b) {
+            if (bin_first) bin_first[b] = (int32_t)total;
+            for (uint32_t k = M.start[2 * b]; k < M.start[2 * b + 1]; ++k) {
+                if (items) items[total] = M.items[k];
+                ++total;
+            }
+        }
+    if (bin_first && M.usable) bin_first[bins] = (int32_t)total;
+    if (n_items) *n_items = total;
+    return RT_OK;
+}
+
 int rt_create(int32_t device, void* stream, RtContext** out) {
     if (!out) return fail(RT_ERR_INVALID, "out is null");
     *out = nullptr;
@@ -954,7 +1002,15 @@ int rt_upload_samples_noalloc(RtContext* ctx, int64_t dst_offset, const double* 
     return RT_OK;
 }
 
-constexpr size_t MT_RAW_KEEP_BYTES = (size_t)64 << 30;
+// The generator's raw words stay with the context between calls up to this size (RT_MT_RAW_KEEP_GB, default 64;
+// 0: never; rt_trim gives them back at any time).
+size_t mt_raw_keep_bytes() {
+    static const size_t limit = [] {
+        const char* e = getenv("RT_MT_RAW_KEEP_GB");
+        return (size_t)(e ? std::max(0.0, atof(e)) : 64.0) << 30;
+    }();
+    return limit;
+}
 int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32_t* key_out, int32_t* pos_out) {
     if (int rc = use_device(ctx)) return rc;
     if (!ctx->layout_set) return fail(RT_ERR_STATE, "rt_set_sample_layout has not been called");
@@ -1120,7 +1176,15 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     // The raw words are only needed while they are being packed, but getting device memory back that
     // some process has used before takes the driver tens of milliseconds per GB (measured: 1.3 s for
     // the 50 GB of a 4K example_4 frame, every call), so a buffer of moderate size stays with the context.
-    if (ctx->mt_raw.n * sizeof(uint32_t) > MT_RAW_KEEP_BYTES) ctx->mt_raw.release();
+    if (ctx->mt_raw.n * sizeof(uint32_t) > mt_raw_keep_bytes()) ctx->mt_raw.release();
+    return RT_OK;
+}
+
+int rt_trim(RtContext* ctx) {
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->mt_raw.release(); ctx->mt_ring.release(); ctx->mt_end.release(); ctx->mt_polys.release();
+    ctx->staging.release(); ctx->hit_mask.release(); ctx->hit_pref.release(); ctx->hit_word0.release(); ctx->emit_blocks.release();
     return RT_OK;
 }
 
@@ -1144,7 +1208,13 @@ int rt_shade(RtContext* ctx) {
     const bool mixed = ctx->precision != RT_PRECISION_F64 && ctx->frame_col32 && ctx->sampled_lights && ctx->S <= MIXED_MAX_SPHERES && ctx->have_packed32;
     const bool check = ctx->precision == RT_PRECISION_MIXED_CHECKED;
     if (mixed && !ctx->disk_points_ready) {
-        // once per sample stream (not per frame): the float32 pass reads disk points, see k_disk_points
+        // once per sample stream (not per frame): the float32 pass reads disk points, see k_disk_points.
+        // Not while the stream is being captured: the kernel would be recorded, not run, and a later
+        // rt_shade outside the graph would find the flag set and the points missing.
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ctx->stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+            return fail(RT_ERR_STATE, "the first rt_shade after new disk-light samples prepares them for the float32 pass and "
+                                      "cannot be captured into a graph: call rt_shade once before the capture");
         for (int l = 0; l < ctx->sc_host.n_lights && ctx->pack_E > 0; ++l) {
             const RtLight& L = ctx->sc_host.lights[l];
             if (L.kind == RT_LIGHT_POINT) continue;

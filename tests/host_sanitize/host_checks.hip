@@ -8,6 +8,7 @@
 //   host_checks hier N SEED             -> grouping of N pseudo-random spheres (+ one huge ground sphere)
 //   host_checks hierfile FILE N         -> grouping of the N spheres stored as doubles [N][4] in FILE
 //   host_checks jump K                  -> 624 words of x^(2^K) mod phi
+//   host_checks grid N SEED             -> uniform grid and point-light occluder map of the same spheres: sizes and checksums
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,8 @@
 #include "../../raytracing_amd/csrc/host_tree.h"
 #include "../../raytracing_amd/csrc/mt_jump.h"
 #include "../../raytracing_amd/csrc/hier_build.h"
+#include "../../raytracing_amd/csrc/grid_build.h"
+#include "../../raytracing_amd/csrc/lightmap_build.h"
 
 template <typename T>
 static void line(const char* name, const std::vector<T>& v) {
@@ -59,6 +62,26 @@ int main(int argc, char** argv) {
         for (int i = 1; i < n; ++i) g.insert(g.end(), {2 + 58 * u(), -25 + 50 * u(), 0.3 + 11.7 * u(), 0.15 + 0.45 * u()});
         return print_hierarchy(g);
     }
+    if (argc >= 4 && !strcmp(argv[1], "grid")) {
+        const int n = atoi(argv[2]);
+        uint64_t s = (uint64_t)atoll(argv[3]) * 6364136223846793005ull + 1442695040888963407ull;
+        auto u = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; };
+        std::vector<double> g;
+        if (n > 0) g.insert(g.end(), {4.0, 0.0, -1.0e7, 1.0e7});
+        for (int i = 1; i < n; ++i) g.insert(g.end(), {2 + 58 * u(), -25 + 50 * u(), 0.3 + 11.7 * u(), 0.15 + 0.45 * u()});
+        const rt::HostGrid G = rt::build_grid(g.data(), g.size() / 4, 2.0);
+        long long sum = 0;
+        for (uint16_t v : G.items) sum += v;
+        printf("dims %d %d %d\nloose %zu\nitems %zu\nitem_sum %lld\n", G.n[0], G.n[1], G.n[2], G.loose.size(), G.items.size(), sum);
+        std::vector<char> in_grid(g.size() / 4, 1);
+        for (uint16_t i : G.loose) in_grid[i] = 0;
+        const double light[3] = {4.0, 20.0, 30.0};
+        const rt::HostLightMap M = rt::build_light_map(g.data(), g.size() / 4, light, in_grid);
+        sum = 0;
+        for (uint16_t v : M.items) sum += v;
+        printf("map_usable %d\nmap_always %zu\nmap_items %zu\nmap_item_sum %lld\n", M.usable ? 1 : 0, M.always.size(), M.items.size(), sum);
+        return 0;
+    }
     if (argc >= 4 && !strcmp(argv[1], "hierfile")) {
         const size_t n = (size_t)atoll(argv[3]);
         std::vector<double> g(n * 4);
@@ -73,6 +96,6 @@ int main(int argc, char** argv) {
         line("poly", w);
         return 0;
     }
-    fprintf(stderr, "usage: host_checks tree|hier|hierfile|jump ...\n");
+    fprintf(stderr, "usage: host_checks tree|hier|hierfile|jump|grid ...\n");
     return 2;
 }

@@ -95,3 +95,14 @@ def test_jump_polynomials_under_sanitizers(checker, k):
 
 def test_jump_polynomial_range_under_sanitizers(checker):
     assert "error" in checker("jump", 48) and "error" in checker("jump", -1)
+
+
+@pytest.mark.parametrize("n", [0, 1, 70, 1500])
+def test_grid_and_light_map_under_sanitizers(checker, n):
+    out = checker("grid", n, 11)
+    dims = [int(v) for v in out["dims"]]
+    if n <= 1:
+        assert int(out["items"][0]) >= 0      # (a scene of one sphere: nothing to check but that it ran clean)
+    else:
+        assert min(dims) >= 1 and int(out["loose"][0]) == 1 and int(out["items"][0]) >= n - 1
+        assert int(out["map_usable"][0]) == 1 and int(out["map_always"][0]) == 1 and int(out["map_items"][0]) >= n - 1
