@@ -336,6 +336,7 @@ int launch_level(RtContext* ctx, int level) {
     const Dev D = ctx->dev();
     ctx->begin(RT_K_TRACE);
     if (ctx->S <= SPH_CHUNK_SMALL) hipLaunchKernelGGL((k_trace<true>), dim3(ctx->nb), dim3(BLOCK), 0, ctx->stream, D, level);
+    else if (ctx->grid_cells) hipLaunchKernelGGL((k_trace<false, true>), dim3(ctx->nb), dim3(BLOCK), 0, ctx->stream, D, level);
     else hipLaunchKernelGGL((k_trace<false>), dim3(ctx->nb), dim3(BLOCK), 0, ctx->stream, D, level);
     ctx->end();
     ctx->begin(RT_K_SCAN);
@@ -1231,7 +1232,10 @@ int rt_shade(RtContext* ctx) {
     else if (mixed && ctx->simple_shading) hipLaunchKernelGGL((k_surface_mixed<true, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
     else if (mixed) hipLaunchKernelGGL((k_surface_mixed<false, false>), dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
     else {
-        auto kernel = lds ? (D.col32 ? k_surface<true, true> : k_surface<true, false>) : (D.col32 ? k_surface<false, true> : k_surface<false, false>);
+        auto kernel = lds ? (D.col32 ? k_surface<true, true> : k_surface<true, false>)
+                          : ctx->sampled_lights ? (D.col32 ? k_surface<false, true> : k_surface<false, false>)
+                          : ctx->grid_cells     ? (D.col32 ? k_surface<false, true, true, true> : k_surface<false, false, true, true>)
+                                                : (D.col32 ? k_surface<false, true, true> : k_surface<false, false, true>);
         hipLaunchKernelGGL(kernel, dim3(NB), dim3(BLOCK), 0, ctx->stream, D);
     }
     if (mixed) hipLaunchKernelGGL((k_surface_redo<true>), dim3(64), dim3(BLOCK), 0, ctx->stream, D);

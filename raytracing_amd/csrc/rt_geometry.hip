@@ -135,7 +135,10 @@ struct SphereRec {   // per-sphere constants of the hit record
     double mu_out, mu_in, r0, ior, floor_, transp, refl_max, pad;
 };
 
-template <bool SMALL>   // SMALL: at most SPH_CHUNK_SMALL spheres, all constants in LDS
+// SMALL: at most SPH_CHUNK_SMALL spheres, all constants in LDS.  GRID (many spheres): the scene has a
+// uniform grid; the other searches (hierarchy, every sphere) are left out of the kernel, which
+// keeps its register demand down.
+template <bool SMALL, bool GRID = false>
 __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY) void k_trace(Dev D, int level) {
     constexpr int SPH_CHUNK = SMALL ? SPH_CHUNK_SMALL : 1;
     __shared__ NodeRec s_node[MAX_LEVEL_NODES];
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
     __shared__ SphereRec s_rec[SMALL ? SPH_CHUNK_SMALL : 1];
     // per lane: the spheres the screening kept (element k of thread t at [k][t])
     static_assert(CAND_MAX <= HIER_CAP, "the plain screening loop uses the same list");
-    __shared__ uint16_t s_list[SMALL ? 1 : 2 * HIER_CAP][SMALL ? 1 : BLOCK];
+    __shared__ uint16_t s_list[SMALL ? 1 : (GRID ? 1 : 2) * HIER_CAP][SMALL ? 1 : BLOCK];   // (the grid's walk uses one list per lane)
     __shared__ SceneConst s_sc;
     static_assert(sizeof(SceneConst) % 8 == 0, "SceneConst is copied in 8-byte words");
 
@@ -332,9 +335,9 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                     if (tt > 0 && (tt < best || (tt == best && i > sid))) { best = tt; sid = i; }
                 }
             };
-            const LaneList list = {&s_list[0][SMALL ? 0 : tid]}, clusters = {&s_list[SMALL ? 0 : HIER_CAP][SMALL ? 0 : tid]};
+            const LaneList list = {&s_list[0][SMALL ? 0 : tid]}, clusters = {&s_list[(SMALL || GRID) ? 0 : HIER_CAP][SMALL ? 0 : tid]};
             bool every_sphere = active;   // lanes that screen the whole table
-            if (D.grid_cells) {
+            if (GRID || D.grid_cells) {
                 // Uniform grid: the spheres outside it first (a hit there bounds the walk), then the
                 // cells along the ray, front to back.  Candidates collect in the lane's list and take
                 // the float64 test together, every few steps or when some lane's list is nearly full; a
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                 for (int k = 0; __ballot(k < n) != 0; ++k)
                     if (k < n) exact(list[k]);
                 every_sphere = false;
-            } else if (D.hier_top_groups) {
+            } else if (!GRID && D.hier_top_groups) {
                 // Bounding-sphere hierarchy: a few dozen tests instead of one per sphere.  The ray
                 // is walked in windows that grow by a factor of 4: most rays of a scene full of
                 // spheres end close to where they start (inside a sphere, at a neighbour), and a
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                 }
                 every_sphere = overflowed;
             }
-            if (every_sphere) {
+            if (!GRID && every_sphere) {
                 // All pairs of the table (read through the scalar unit, four pairs per step).  The
                 // survivors of a lane go to its own short list first and are tested together
                 // afterwards, in sphere order: lanes survive at different spheres, testing on the

@@ -40,7 +40,8 @@ struct ShadowLists {   // per-lane lists in LDS for the screening of many sphere
     LaneList clusters, spheres;
 };
 // `light`: index of the point light the ray goes to, or -1 (a sample of a disk light).
-template <bool LDS>
+// GRID (many spheres): the scene has a uniform grid, the other searches are left out.
+template <bool LDS, bool GRID = false>
 __device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere* s_sh, const ShadowLists& lists, V3 o, V3 d, int light) {
     V3 mult = {1, 1, 1};
     const int S = D.S;
@@ -71,7 +72,7 @@ __device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere
             }
         };
         bool every_sphere = true;   // this lane screens the whole table
-        if (D.grid_cells) {
+        if (GRID || D.grid_cells) {
             // uniform grid: the spheres outside it and the survivors of the cells along the whole ray,
             // then ascending sphere order (the order of the multiplications), every sphere once
             const LaneList cand = lists.spheres;
@@ -150,7 +151,7 @@ __device__ __forceinline__ V3 shadow_multiplier(const Dev& D, const ShadowSphere
             }
             every_sphere = overflow;
             if (overflow) { mult = {1, 1, 1}; opaque = false; }
-        } else if (D.hier_top_groups) {
+        } else if (!GRID && D.hier_top_groups) {
             // the ray starts at -dot(ref - o, d) on the line, measured from `on`; rounded down
             const double s_o = -dot(ref - o, d);
             const float s_from = (float)(s_o - 1e-6 * fabs(s_o)) - e_ray;
@@ -246,7 +247,7 @@ __device__ __forceinline__ double ease(int mode, double x, double a, double d) {
 struct SampleTerms {
     V3 Id, Is, kd, ks;
 };
-template <bool LDS>
+template <bool LDS, bool GRID = false>
 __device__ SampleTerms disk_sample_f64(const Dev& D, const ShadowSphere* s_sh, const ShadowLists& cand, const RtLight& Lt, double u_theta,
                                        double u_rad, V3 Pb, V3 d, V3 n, V3 kdiff, V3 kspec, double shin) {
     const V3 lpos = ld3(Lt.position), xh = ld3(Lt.x_hat), yh = ld3(Lt.y_hat);
@@ -258,7 +259,7 @@ __device__ SampleTerms disk_sample_f64(const Dev& D, const ShadowSphere* s_sh, c
     V3 Lv = lp - Pb;
     const double dist = sqrt(dot(Lv, Lv));
     V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
-    V3 mult = shadow_multiplier<LDS>(D, s_sh, cand, Pb, Lh, -1);
+    V3 mult = shadow_multiplier<LDS, GRID>(D, s_sh, cand, Pb, Lh, -1);
     const double fall = (Lt.intensity / Lt.n_points) / (dist * dist);
     SampleTerms o;
     o.Id = clip01((fall * ld3(Lt.diffuse_color)) * mult);
@@ -275,7 +276,9 @@ __device__ SampleTerms disk_sample_f64(const Dev& D, const ShadowSphere* s_sh, c
 // Surface colour of one hit under all lights in float64 (reference raytrace.py:136-152,
 // :215-234 and objects.py:94-235).  entry: index of the hit in the shading list,
 // which is also the index of its disk-light samples in the packed sample buffer.
-template <bool LDS>
+// POINT_ONLY: the scene has no sampled (disk, spot) light; their code is left out, which keeps the
+// many-sphere kernel's register demand down.
+template <bool LDS, bool POINT_ONLY = false, bool GRID = false>
 __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphere* s_sh, const ShadowLists& cand, int64_t entry, uint32_t info,
                             V3 Pb, V3 d, V3 n, const SurfaceMaterial& mat, unsigned& n_samples) {
     const V3 kdiff = ld3(mat.kdiff), kspec = ld3(mat.kspec);
@@ -290,7 +293,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
             const double d2 = dot(Lv, Lv);
             const double dist = sqrt(d2);
             V3 Lh = {Lv.x / dist, Lv.y / dist, Lv.z / dist};
-            V3 mult = shadow_multiplier<LDS>(D, s_sh, cand, Pb, Lh, l);
+            V3 mult = shadow_multiplier<LDS, GRID>(D, s_sh, cand, Pb, Lh, l);
             const double fall = Lt.intensity / (dist * dist);
             V3 Id = clip01((fall * dcol) * mult), Is = clip01((fall * scol) * mult);
             const double nl = dot(n, Lh);
@@ -301,6 +304,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
             n_samples += 1;
             continue;
         }
+        if constexpr (POINT_ONLY) continue;
         // disk light, possibly restricted to a beam
         double factor = 1.0;
         if (Lt.kind == RT_LIGHT_SPOT) {
@@ -318,7 +322,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
         const int64_t stride = D.pack_E;
         V3 sumId = {0, 0, 0}, sumIs = {0, 0, 0}, sumKd = {0, 0, 0}, sumKs = {0, 0, 0};
         for (int s = 0; s < N; ++s) {
-            const SampleTerms o = disk_sample_f64<LDS>(D, s_sh, cand, Lt, pk[s * stride], pk[D.pack_plane + s * stride],
+            const SampleTerms o = disk_sample_f64<LDS, GRID>(D, s_sh, cand, Lt, pk[s * stride], pk[D.pack_plane + s * stride],
                                                        Pb, d, n, kdiff, kspec, shin);
             sumId = sumId + o.Id; sumIs = sumIs + o.Is; sumKd = sumKd + o.kd; sumKs = sumKs + o.ks;
         }
@@ -336,7 +340,7 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
 
 // ---------------------------------------------------------------------------------------------
 // Lighting in float64 for the dense list of hits whose surface colour matters (all levels).
-template <bool LDS, bool C32>   // C32: surface colours stored as float32 (Dev::col32)
+template <bool LDS, bool C32, bool POINT_ONLY = false, bool GRID = false>   // C32: surface colours stored as float32 (Dev::col32)
 __global__ __launch_bounds__(BLOCK, LDS ? RT_SURFACE_WAVES : RT_SURFACE_WAVES_MANY) void k_surface(Dev D) {
     constexpr int TABLE = LDS ? SHADE_LDS_SPHERES : 1;
     __shared__ ShadowSphere s_sh[TABLE];
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(BLOCK, LDS ? RT_SURFACE_WAVES : RT_SURFACE_WAVES_MA
         const V3 centre = LDS ? V3{s_centre[sid][0], s_centre[sid][1], s_centre[sid][2]} : ld3(D.geom + (size_t)sid * 4);
         const SurfaceMaterial mat = LDS ? s_mat[sid] : surface_material(D.mat + (size_t)sid * RT_MAT_WIDTH);
         const Surface sf = surface_at(P, centre, info & I_INSIDE, eps);
-        V3 surf = surface_color<LDS>(D, sc, s_sh, lists, e, info, sf.Pb, d, sf.n, mat, my_samples);
+        V3 surf = surface_color<LDS, POINT_ONLY, GRID>(D, sc, s_sh, lists, e, info, sf.Pb, d, sf.n, mat, my_samples);
         my_hits += 1;
         store_smooth(D.sr, e, surf.x, C32); store_smooth(D.sg, e, surf.y, C32); store_smooth(D.sb, e, surf.z, C32);
         e = e_next;
