@@ -17,6 +17,7 @@ struct HostGrid {
     std::vector<uint16_t> loose;    // spheres kept out of the grid: always tested
     double origin[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // the box: [0, hi] relative to origin
     float h = 0, inv_h = 0;
+    float margin = 0;               // what a sphere's radius is enlarged by when it is registered (plus its own rounding terms)
     int n[3] = {0, 0, 0};
     int cells() const { return n[0] * n[1] * n[2]; }
 };
@@ -66,6 +67,7 @@ inline HostGrid build_grid(const double* geom, size_t S, double density) {
     G.h = (float)h;
     h = (double)G.h;   // the device divides by this value
     G.inv_h = (float)(1.0 / h);
+    G.margin = (float)(GRID_SLACK * h + GRID_DRIFT * longest);
     const size_t cells = (size_t)G.cells();
     // every sphere into the cells its enlarged ball reaches
     std::vector<std::vector<uint16_t>> lists(cells);
@@ -76,7 +78,7 @@ inline HostGrid build_grid(const double* geom, size_t S, double density) {
     for (uint32_t i : in) {
         const double c[3] = {geom[i * 4] - G.origin[0], geom[i * 4 + 1] - G.origin[1], geom[i * 4 + 2] - G.origin[2]};
         const double l1 = fabs(c[0]) + fabs(c[1]) + fabs(c[2]);
-        const double R = radii[i] * (1 + 4e-6) + GRID_SLACK * h + 1e-5 * (l1 + longest);
+        const double R = radii[i] * (1 + 4e-6) + G.margin + 1e-5 * l1;
         int a[3], b[3];
         for (int k = 0; k < 3; ++k) cell_range(c[k], R, k, a[k], b[k]);
         const size_t reach = (size_t)(b[0] - a[0] + 1) * (b[1] - a[1] + 1) * (b[2] - a[2] + 1);

@@ -179,7 +179,7 @@ struct RtContext {
     int lmap_start_off[RT_MAX_LIGHTS] = {0}, lmap_always_off[RT_MAX_LIGHTS] = {0}, lmap_n_always[RT_MAX_LIGHTS] = {0};
     uint32_t lmap_mask = 0;
     int grid_cells = 0, grid_n_loose = 0, grid_n[3] = {0, 0, 0};
-    float grid_h = 0, grid_inv_h = 0;
+    float grid_h = 0, grid_inv_h = 0, grid_margin = 0;
     double grid_origin[3] = {0, 0, 0}, grid_hi[3] = {0, 0, 0};
     DevBuf<SceneConst> sc;
     DevBuf<int32_t> node_a, node_b, node_branch, node_child, level_start;
@@ -247,7 +247,7 @@ struct RtContext {
         D.geom = geom.p; D.mat = mat.p; D.fres = fres.p; D.cull = cull.p; D.cull_ref[0] = cull_ref[0]; D.cull_ref[1] = cull_ref[1]; D.cull_ref[2] = cull_ref[2]; D.sc = sc.p; D.S = S; D.n_lights = sc_host.n_lights;
         D.hier_top = hier_top.p; D.hier_top_ref = hier_top_ref.p; D.hier_mid = hier_mid.p; D.hier_leaf = hier_leaf.p; D.hier_ids = hier_ids.p; D.hier_top_groups = hier_top_groups; D.hier_blocks = hier_blocks; D.hier_window = hier_window; D.hier_extent = hier_extent;
         D.grid_start = grid_start.p; D.grid_items = grid_items.p; D.grid_sph = reinterpret_cast<const float4*>(grid_sph.p); D.grid_loose = grid_loose.p;
-        D.grid_n_loose = grid_n_loose; D.grid_cells = grid_cells; D.grid_h = grid_h; D.grid_inv_h = grid_inv_h;
+        D.grid_n_loose = grid_n_loose; D.grid_cells = grid_cells; D.grid_h = grid_h; D.grid_inv_h = grid_inv_h; D.grid_margin = grid_margin;
         for (int k = 0; k < 3; ++k) { D.grid_n[k] = grid_n[k]; D.grid_origin[k] = grid_origin[k]; D.grid_hi[k] = grid_hi[k]; }
         D.lmap_start = lmap_start.p; D.lmap_items = lmap_items.p; D.lmap_always = lmap_always.p; D.lmap_mask = lmap_mask;
         for (int l = 0; l < RT_MAX_LIGHTS; ++l) { D.lmap_start_off[l] = lmap_start_off[l]; D.lmap_always_off[l] = lmap_always_off[l]; D.lmap_n_always[l] = lmap_n_always[l]; }
@@ -656,7 +656,7 @@ int rt_set_scene(RtContext* ctx, const RtScene* scene, const RtParams* params) {
                 HIP_TRY(upload(ctx->grid_loose, G.loose));
                 ctx->grid_cells = G.cells();
                 ctx->grid_n_loose = (int)G.loose.size();
-                ctx->grid_h = G.h; ctx->grid_inv_h = G.inv_h;
+                ctx->grid_h = G.h; ctx->grid_inv_h = G.inv_h; ctx->grid_margin = G.margin;
                 for (int k = 0; k < 3; ++k) { ctx->grid_n[k] = G.n[k]; ctx->grid_origin[k] = G.origin[k]; ctx->grid_hi[k] = G.hi[k]; }
                 // point lights: their occluders by direction (RT_LIGHT_MAPS=0: shadow rays walk the grid)
                 const char* use_maps = getenv("RT_LIGHT_MAPS");

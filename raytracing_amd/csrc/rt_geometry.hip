@@ -349,7 +349,7 @@ __global__ __launch_bounds__(BLOCK, SMALL ? RT_TRACE_WAVES : RT_TRACE_WAVES_MANY
                 GridWalk w = grid_begin(D, active, o, d);
                 int n = 0;
                 auto push = [&](uint32_t id) { list[n++] = (uint16_t)id; };   // two free places are kept
-                const float slack = (float)(2 * GRID_SLACK) * D.grid_h;
+                const float slack = 2 * D.grid_margin;
                 auto reach = [&]() -> float {
                     if (!(best < __builtin_inf())) return w.t_out;
                     return fminf(w.t_out, (float)((best - w.enter) * 1.000001) + slack);

@@ -10,13 +10,16 @@
 //
 // Why no sphere that the exact ray touches is lost.  All float32 coordinates are relative to the
 // grid's own origin and the walk starts where the ray enters the grid's box (computed in float64),
-// so the float32 line stays within about 1e-5 units of the exact one inside a box of some tens of units,
-// and the planes a cell boundary is compared with are computed afresh from the cell's integer
-// index at every step (no accumulated sums).  The cells the walk visits therefore cover the exact
-// ray up to a distance far below GRID_SLACK cell sizes; every sphere is registered with its radius
-// enlarged by that slack (plus its own rounding terms), so a point of the exact ray inside the
-// sphere lies in (or within the slack of) a visited cell that lists the sphere.  The screening
-// itself uses the error terms derived above cull_test.
+// so the float32 line stays within a few 1e-7 of the box's extent of the exact one inside the box.
+// The place of the next cell boundary along an axis is kept as a running sum (one float32 addition
+// per step along that axis): after at most 3 * GRID_MAX_AXIS steps it is off by less than
+// 768 * 2^-24 of the ray's length inside the box, i.e. below 8e-5 of the box's extent.  A walk whose
+// boundaries are off by that much visits cells that cover the exact ray up to that distance (a
+// corner may be passed on the other side).  Every sphere is therefore registered with its radius
+// enlarged by the grid's margin - GRID_SLACK cell sizes plus GRID_DRIFT of the box's extent plus
+// its own rounding terms - so a point of the exact ray inside the sphere lies in, or within the
+// margin of, a visited cell that lists the sphere; the same margin is allowed for when a walk ends
+// at a known hit.  The screening itself uses the error terms derived above cull_test.
 #pragma once
 #include <math.h>
 
@@ -26,6 +29,7 @@
 namespace rt {
 
 constexpr double GRID_SLACK = 1e-3;          // registration slack, in cell sizes
+constexpr double GRID_DRIFT = 2e-4;          // ... plus this fraction of the box's longest side (drift of the walk's running sums)
 constexpr int GRID_MAX_AXIS = 256;           // cells along one axis at most
 constexpr int GRID_LIST = 16;                // candidates a lane collects before the wave tests them
 static_assert(GRID_LIST == HIER_CAP, "the walk uses the per-lane lists of the hierarchy");
@@ -40,6 +44,8 @@ struct GridWalk {
     float e_ray;             // this ray's part of the screening's error bound
     float t_out;             // where the ray leaves the box (rounded up)
     float tmx, tmy, tmz;     // where the ray crosses the next cell boundary along each axis
+    float dtx, dty, dtz;     // from one boundary to the next along each axis (inf for a zero component)
+    int sx, sy, sz;          // direction of the steps
     int cx, cy, cz;          // current cell
     uint32_t cur, end;       // items of the current cell still to screen
     double enter;            // ray parameter of the entry point
@@ -55,6 +61,7 @@ __device__ __forceinline__ GridWalk grid_begin(const Dev& D, bool active, V3 o, 
     w.enter = 0;
     w.t_out = 0;
     w.px = w.py = w.pz = 0; w.dx = 1; w.dy = w.dz = 0; w.ix_ = w.iy_ = w.iz_ = 0; w.e_ray = 0; w.tmx = w.tmy = w.tmz = 0;
+    w.dtx = w.dty = w.dtz = 0; w.sx = w.sy = w.sz = 1;
     if (!active) return w;
     // the box, enlarged by the slack, against the ray in float64
     const double slack = GRID_SLACK * (double)D.grid_h;
@@ -88,6 +95,8 @@ __device__ __forceinline__ GridWalk grid_begin(const Dev& D, bool active, V3 o, 
     w.tmx = w.dx == 0 ? __builtin_inff() : ((float)(w.cx + (w.dx > 0 ? 1 : 0)) * h - w.px) * w.ix_;
     w.tmy = w.dy == 0 ? __builtin_inff() : ((float)(w.cy + (w.dy > 0 ? 1 : 0)) * h - w.py) * w.iy_;
     w.tmz = w.dz == 0 ? __builtin_inff() : ((float)(w.cz + (w.dz > 0 ? 1 : 0)) * h - w.pz) * w.iz_;
+    w.dtx = fabsf(h * w.ix_); w.dty = fabsf(h * w.iy_); w.dtz = fabsf(h * w.iz_);
+    w.sx = w.dx > 0 ? 1 : -1; w.sy = w.dy > 0 ? 1 : -1; w.sz = w.dz > 0 ? 1 : -1;
     const uint32_t cell = ((uint32_t)w.cz * D.grid_n[1] + w.cy) * D.grid_n[0] + w.cx;
     const uint2 se = *reinterpret_cast<const uint2*>(D.grid_start + 2 * (size_t)cell);
     w.cur = se.x; w.end = se.y;
@@ -109,23 +118,14 @@ __device__ __forceinline__ void grid_step(const Dev& D, GridWalk& w, float limit
         w.cur += 2;
     }
     if (w.cur >= w.end) {
-        // next cell: across the nearest boundary (its list is requested before the screening below)
+        // next cell: across the nearest boundary (its list is requested before the screening below);
+        // without branches: one of the three axes takes the step
         const float t_next = fminf(w.tmx, fminf(w.tmy, w.tmz));
-        const float h = D.grid_h;
-        bool out = !(t_next <= limit);
-        if (w.tmx <= w.tmy && w.tmx <= w.tmz) {
-            w.cx += w.dx > 0 ? 1 : -1;
-            out = out || (unsigned)w.cx >= (unsigned)D.grid_n[0];
-            w.tmx = ((float)(w.cx + (w.dx > 0 ? 1 : 0)) * h - w.px) * w.ix_;
-        } else if (w.tmy <= w.tmz) {
-            w.cy += w.dy > 0 ? 1 : -1;
-            out = out || (unsigned)w.cy >= (unsigned)D.grid_n[1];
-            w.tmy = ((float)(w.cy + (w.dy > 0 ? 1 : 0)) * h - w.py) * w.iy_;
-        } else {
-            w.cz += w.dz > 0 ? 1 : -1;
-            out = out || (unsigned)w.cz >= (unsigned)D.grid_n[2];
-            w.tmz = ((float)(w.cz + (w.dz > 0 ? 1 : 0)) * h - w.pz) * w.iz_;
-        }
+        const bool bx = w.tmx <= w.tmy && w.tmx <= w.tmz, by = !bx && w.tmy <= w.tmz, bz = !bx && !by;
+        w.cx += bx ? w.sx : 0; w.cy += by ? w.sy : 0; w.cz += bz ? w.sz : 0;
+        w.tmx += bx ? w.dtx : 0.0f; w.tmy += by ? w.dty : 0.0f; w.tmz += bz ? w.dtz : 0.0f;
+        const bool out = !(t_next <= limit) || (unsigned)w.cx >= (unsigned)D.grid_n[0] || (unsigned)w.cy >= (unsigned)D.grid_n[1] ||
+                         (unsigned)w.cz >= (unsigned)D.grid_n[2];
         if (out) {
             w.done = true;
         } else {

@@ -96,6 +96,7 @@ struct Dev {
     int32_t grid_cells;
     int32_t grid_n[3];             // cells along x, y, z
     float grid_h, grid_inv_h;      // cell size
+    float grid_margin;             // what the spheres' radii were enlarged by at registration (rt_grid.h)
     double grid_origin[3];         // the grid's box is [0, grid_hi] relative to this point
     double grid_hi[3];
     // occluders of the point lights by direction (lightmap_build.h); bit l of lmap_mask: light l has a map
