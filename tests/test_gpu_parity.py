@@ -559,21 +559,32 @@ def test_float32_samples_general_coefficients():
 
 
 # ---------------------------------------------------------------------------------------------
-# The bounding-sphere hierarchy over many spheres only chooses which spheres take the float64 test;
-# with it (default) and without it (RT_HIERARCHY=0: every sphere screened for every ray) the frame
-# must come out bit for bit the same: images, ray and hit counts.
-def _with_and_without_hierarchy(flat, width, height):
+# What is built over many spheres - the uniform grid with the point lights' occluder maps (default),
+# the grid alone (RT_LIGHT_MAPS=0), the bounding-sphere hierarchy (RT_ACCEL=hier) - only chooses
+# which spheres take the float64 test; with each of them and with none (RT_HIERARCHY=0: every sphere
+# screened for every ray) the frame must come out bit for bit the same: images, ray and hit counts.
+ACCELERATORS = {"grid": {}, "grid, no light maps": {"RT_LIGHT_MAPS": "0"}, "hierarchy": {"RT_ACCEL": "hier"},
+                "none": {"RT_HIERARCHY": "0"}}
+
+
+def _with_and_without_hierarchy(flat, width, height, which=("grid", "none")):
+    """Frame and counts per accelerator; the keys "1" and "0" stand for the first and the last of ``which``."""
     out = {}
-    for flag in ("1", "0"):
-        os.environ["RT_HIERARCHY"] = flag
+    for name in which:
+        os.environ.update(ACCELERATORS[name])
         try:
             with Renderer(flat, RenderParams(width=width, height=height), precision="f64") as r:
                 r.begin_rows(0, height)
                 img = r.render_pixels()
                 c = r.counters()
-                out[flag] = (img, int(c["rays"]), int(c["hits"]), int(c["shaded_hits"]))
+                out[name] = (img, int(c["rays"]), int(c["hits"]), int(c["shaded_hits"]))
         finally:
-            os.environ.pop("RT_HIERARCHY", None)
+            for key in ACCELERATORS[name]:
+                os.environ.pop(key, None)
+    for name in which[1:-1]:
+        assert out[name][1:] == out[which[-1]][1:], name
+        assert np.array_equal(out[name][0], out[which[-1]][0]), name
+    out["1"], out["0"] = out[which[0]], out[which[-1]]
     return out
 
 
@@ -583,9 +594,46 @@ def test_hierarchy_matches_plain_screening(n_spheres):
     from raytracing_amd.flatten import flatten_scene
     w, h = (256, 144) if n_spheres <= 1000 else (128, 72)
     flat = flatten_scene(synthetic.many_spheres_scene(n_spheres, w, h))
-    out = _with_and_without_hierarchy(flat, w, h)
+    out = _with_and_without_hierarchy(flat, w, h, tuple(ACCELERATORS))
     assert out["1"][1:] == out["0"][1:]
     assert np.array_equal(out["1"][0], out["0"][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("light", ["disk", "spot", "point + disk"])
+def test_many_spheres_under_sampled_lights(light):
+    """More than 64 spheres under a disk light or a spotlight: the shadow rays of the samples walk the
+    grid (no occluder map: that is for point lights), in float64.  Against the oracle, and every
+    accelerator against none."""
+    from raytracing_amd import objects
+    from raytracing_amd.flatten import flatten_scene
+    w, h = 64, 36
+    scene = synthetic.many_spheres_scene(90, w, h)
+    point = scene.light_sources[0]
+    if light == "spot":
+        sampled = objects.DirectionalDiskSource(x=20, y=0, z=25, radius=2, intensity=900, angle=40, easing_mode="linear")
+        sampled.n_points = 3
+    else:
+        sampled = objects.DiskSource(x=20, y=5, z=25, radius=3, intensity=900, N=3)
+    scene.light_sources = [point, sampled] if light.startswith("point") else [sampled]
+    flat = flatten_scene(scene)
+    want, stats = O.render(flat, seed=3)
+    frames = {}
+    for name, env in ACCELERATORS.items():
+        os.environ.update(env)
+        try:
+            np.random.seed(3)
+            with Renderer(flat, RenderParams(width=w, height=h), precision="f64") as r:
+                r.begin_rows(0, h)
+                frames[name] = r.render_pixels()
+                c = r.counters()
+            assert int(c["rays"]) == stats.traced_rays() and int(c["hits"]) == stats.hits(), name
+        finally:
+            for key in env:
+                os.environ.pop(key, None)
+    assert np.abs(frames["grid"] - want.reshape(-1, 3)).max() <= 1e-8
+    for name in frames:
+        assert np.array_equal(frames[name], frames["none"]), name
 
 
 @pytest.mark.gpu
@@ -606,7 +654,7 @@ def test_hierarchy_far_from_origin_and_list_overflow():
     flat.sphere_mat = np.vstack([flat.sphere_mat, glass])
     for shift in ((0, 0, 0), (1.0e5, -2.0e5, 3.0e4)):
         f = _shifted(flat, shift)
-        out = _with_and_without_hierarchy(f, 96, 54)
+        out = _with_and_without_hierarchy(f, 96, 54, tuple(ACCELERATORS))
         assert out["1"][1:] == out["0"][1:]
         assert np.array_equal(out["1"][0], out["0"][0])
     want, stats = O.render(flat, seed=0)
@@ -667,9 +715,10 @@ def test_benchmark_size_properties(name):
 
 @pytest.mark.gpu
 def test_hierarchy_matches_plain_screening_at_full_size():
-    """The 4096-sphere scene at 3840x2160 (482 M rays): the search through the bounding-sphere hierarchy and
-    the plain screening of every (ray, sphere) pair - two different ways to the candidates of the float64
-    test - give the same frame bit for bit and the same ray, hit and shaded-hit counts.  (The pin of this
+    """The 4096-sphere scene at 3840x2160 (482 M rays): the walk through the grid (with the point
+    light's occluder map) and the plain screening of every (ray, sphere) pair - two different ways to
+    the candidates of the float64 test - give the same frame bit for bit and the same ray, hit and
+    shaded-hit counts.  (The pin of this
     scene to the reference is the 64x36 golden, test_many_spheres_4096_through_the_hierarchy: the
     reference needs 290 s for that size.)"""
     from raytracing_amd.flatten import flatten_scene

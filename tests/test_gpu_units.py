@@ -115,3 +115,56 @@ def test_screen_points_and_primary_directions(kats):
         d = want - flat.camera_position
         d = d / np.linalg.norm(d, axis=-1, keepdims=True)
         assert np.array_equal(got[:, 3:], d), name
+
+
+def test_trim_gives_the_sample_work_buffers_back():
+    """rt_trim releases what the sample calls keep between frames (raw words of the generator, staging),
+    and the next frame simply allocates again and reproduces the image."""
+    import torch
+    from raytracing_amd.raytrace import Renderer
+    scene = build_scene("example_4", 320, 180)
+    with Renderer(scene) as r:
+        r.begin_rows(0, 180)
+        np.random.seed(5)
+        first = r.render_pixels().copy()
+        r.ctx.synchronize()
+        held = torch.cuda.mem_get_info(0)[0]
+        r.ctx.trim()
+        assert torch.cuda.mem_get_info(0)[0] > held
+        np.random.seed(5)
+        assert np.array_equal(r.render_pixels(), first)
+
+
+def test_first_shade_after_new_samples_is_refused_under_stream_capture():
+    """The first rt_shade after new disk-light samples converts them for the float32 pass; recorded into a
+    graph that conversion would not run when a later, uncaptured rt_shade expects it.  The call refuses
+    (nothing is launched), and after one eager rt_shade the capture works and replays the frame."""
+    import torch
+    from raytracing_amd.raytrace import Renderer
+    scene = build_scene("example_4", 160, 90)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        with Renderer(scene, stream=stream.cuda_stream) as r:
+            r.begin_rows(0, 90)
+            np.random.seed(2)
+            r.trace()
+            r.draw_samples()
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(capture_error_mode="relaxed")
+            try:
+                with pytest.raises(_native.RtError, match="captured"):
+                    r.ctx.shade()
+            finally:
+                g.capture_end()
+            r.ctx.shade()
+            want = r.image().copy()
+            g2 = torch.cuda.CUDAGraph()
+            g2.capture_begin(capture_error_mode="relaxed")
+            try:
+                r.ctx.trace_geometry()
+                r.ctx.shade()
+            finally:
+                g2.capture_end()
+            g2.replay()
+            stream.synchronize()
+            assert np.array_equal(r.image(), want)
