@@ -1126,13 +1126,38 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         // start windows of streams 1 .. T-1 by jump-ahead from the key block
         int n_polys = 1;                                   // bits of T - 1, the largest t
         while (((T - 1) >> n_polys) > 0) ++n_polys;
-        std::vector<uint32_t> polys((size_t)n_polys * MT_N);
-        for (int b = 0; b < n_polys; ++b)
-            if (!mtjump::pow2_words(ell + b, polys.data() + (size_t)b * MT_N))
+        // every polynomial as the list of its set coefficients, round by round (JumpPoly in rt_samples.hip)
+        std::vector<uint32_t> words(MT_N);
+        std::vector<JumpPoly> heads(n_polys);
+        std::vector<uint32_t> lists;
+        for (int b = 0; b < n_polys; ++b) {
+            if (!mtjump::pow2_words(ell + b, words.data()))
                 return fail(RT_ERR_INVALID, "MT19937 jump tables unavailable (stream too long?)");
+            std::vector<uint16_t> index;
+            for (int r = 0; r < MTJ_ROUNDS; ++r) {
+                heads[b].first[r] = (int32_t)(lists.size() + index.size() / 2);
+                for (int i = r * MTJ_CHUNK; i < std::min((r + 1) * MTJ_CHUNK, 19937); ++i)
+                    if ((words[i >> 5] >> (i & 31)) & 1u) index.push_back((uint16_t)i);
+                while (index.size() % 16) index.push_back((uint16_t)MTJ_NONE);
+            }
+            for (size_t i = 0; i < index.size(); i += 2) lists.push_back((uint32_t)index[i] | ((uint32_t)index[i + 1] << 16));
+            heads[b].first[MTJ_ROUNDS] = (int32_t)lists.size();
+        }
+        // (one buffer: the heads, then the lists, 16-byte aligned)
+        const size_t head_words = (n_polys * sizeof(JumpPoly) / 4 + 3) / 4 * 4;
+        std::vector<uint32_t> polys(head_words + lists.size() + 8, 0u);
+        memcpy(polys.data(), heads.data(), n_polys * sizeof(JumpPoly));
+        memcpy(polys.data() + head_words, lists.data(), lists.size() * 4);
         HIP_TRY(ctx->mt_polys.ensure(polys.size()));
         HIP_TRY(hipMemcpy(ctx->mt_polys.p, polys.data(), polys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_mt_jump, dim3(T - 1), dim3(640), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, ctx->mt_polys.p, n_polys, ell);
+        const uint32_t* device_lists = ctx->mt_polys.p + head_words;
+        // level b: the windows of streams 2^b .. min(2^(b+1), T) - 1 from those of streams 0 .. (one polynomial each)
+        for (int b = 0; b < n_polys; ++b) {
+            const int count = std::min(1 << b, T - (1 << b));
+            if (count > 0)
+                hipLaunchKernelGGL(k_mt_jump, dim3(count), dim3(640), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p,
+                                   reinterpret_cast<const JumpPoly*>(ctx->mt_polys.p), device_lists, b, ell);
+        }
     }
     // The state NumPy would be left in: the key block that holds the last word consumed and
     // the position after it (a position of 624 means "regenerate at the next draw").

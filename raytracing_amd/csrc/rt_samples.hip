@@ -488,35 +488,50 @@ __global__ __launch_bounds__(256) void k_mt_emit(Dev D, uint32_t* rings, long lo
     if (tid == 0) gen_ends[t] = g;
 }
 
-// Jump-ahead.  Workgroup blockIdx.x makes the start window of stream t = blockIdx.x + 1:
-// the window at word index t L, reached from the caller's key block (the window at index 0, in
-// ring 0, which must not have generated yet) by applying, for every set bit b of t, the
-// polynomial x^(L 2^b) mod phi:  new window word j = XOR over set coefficients i of s[i + j],
-// s the sequence generated from the current window.  The low 31 bits of the new window's
-// first word are not meaningful (nothing reads them: the previous stream delivers that
-// word).  polys: [n_polys][624] coefficient words, polys[b] = x^(L 2^b) mod phi.
+// Jump-ahead.  The start window of stream t is the window at word index t L.  A window is moved
+// J words ahead by the polynomial x^J mod phi:  new window word j = XOR over set coefficients i of
+// s[i + j], s the sequence generated from the current window.  The low 31 bits of the new window's
+// first word are not meaningful (nothing reads them: the previous stream delivers that word, and the
+// recurrence itself only uses the top bit of a window's first word, so such a window can be moved
+// on again).  polys: [n_polys][624] coefficient words, polys[b] = x^(L 2^b) mod phi.
+//
+// The windows are made level by level, one launch per level b = 0, 1, ...: workgroup blockIdx.x of
+// level b makes the window of stream t = 2^b + blockIdx.x from the window of stream t - 2^b (stream
+// 0: the caller's key block in ring 0, which must not have generated yet) with the one polynomial
+// polys[b] - one application per stream instead of one per set bit of t.
 constexpr int MTJ_RING = 4096, MTJ_CHUNK = 8 * MT_STEP;   // coefficients consumed per round
-__global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen_ends, const uint32_t* polys, int n_polys, int ell) {
+constexpr int MTJ_ROUNDS = (19937 + MTJ_CHUNK - 1) / MTJ_CHUNK;
+// A polynomial as the list of its set coefficients (what k_mt_jump walks; pulling them out of the
+// coefficient words bit by bit cost more scalar instructions than the sums cost vector ones):
+// index[] ascending, two per 32-bit word, padded per round to a multiple of 16 with MTJ_NONE;
+// first[r] = first word of round r's coefficients (those in [r MTJ_CHUNK, (r + 1) MTJ_CHUNK)).
+constexpr uint32_t MTJ_NONE = 0xFFFFu;
+struct JumpPoly {
+    int32_t first[MTJ_ROUNDS + 1];
+};
+__global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen_ends, const JumpPoly* heads, const uint32_t* lists, int level, int ell) {
     __shared__ uint32_t xs[MTJ_RING];     // s[i] at slot i & 4095
-    __shared__ uint32_t coef[MT_N];
     __shared__ uint32_t win[MT_N];
+    typedef const __attribute__((address_space(4))) uint32_t* ConstList;   // uniform reads through the scalar unit
     const int tid = threadIdx.x;
-    const int t = blockIdx.x + 1;
+    const int t = (1 << level) + blockIdx.x;
     const long long L = 1ll << ell;
-    // base window = x[0 .. 623]
-    for (int j = tid; j < MT_N; j += 640) win[j] = rings[j];
+    // the source window: x[u L .. u L + 623] of stream u = t - 2^level, in that stream's ring
+    {
+        const int u = t - (1 << level);
+        const long long from = (long long)u * L;
+        for (int j = tid; j < MT_N; j += 640) win[j] = rings[(size_t)u * MT_RING + ((from + j) & (MT_RING - 1))];
+    }
     __syncthreads();
-    for (int b = 0; b < n_polys; ++b) {
-        if (!(((unsigned)t >> b) & 1u)) continue;      // uniform
-        for (int j = tid; j < MT_N; j += 640) {
-            xs[j] = win[j];
-            coef[j] = polys[(size_t)b * MT_N + j];
-        }
+    {
+        for (int j = tid; j < MT_N; j += 640) xs[j] = win[j];
         __syncthreads();
+        const JumpPoly& head = heads[level];
         uint32_t acc = 0;
         uint32_t prev = (tid < MT_STEP) ? xs[MT_N - MT_STEP + tid] : 0u;   // own-chain value s[gen - 227 + tid]
         int gen = MT_N;                                                     // s[0 .. gen) exist
-        for (int c0 = 0; c0 < 19937; c0 += MTJ_CHUNK) {
+        for (int r = 0; r < MTJ_ROUNDS; ++r) {
+            const int c0 = r * MTJ_CHUNK;
             // make s available up to c0 + MTJ_CHUNK + 623
             while (gen < c0 + MTJ_CHUNK + MT_N) {
                 if (tid < MT_STEP) {
@@ -530,20 +545,21 @@ __global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen
                 gen += 2 * MT_STEP;
                 __syncthreads();
             }
-            // accumulate the coefficients c0 .. c0 + MTJ_CHUNK
+            // accumulate this round's coefficients, sixteen at a time: their reads are in flight together
             if (tid < MT_N) {
-                const int c1 = min(c0 + MTJ_CHUNK, 19937);
-                for (int w = c0 >> 5; w <= (c1 - 1) >> 5; ++w) {
-                    uint32_t bits = __builtin_amdgcn_readfirstlane(coef[w]);
-                    // keep only coefficients inside [c0, c1)
-                    const int lo = w << 5;
-                    if (lo < c0) bits &= ~0u << (c0 - lo);
-                    if (lo + 32 > c1) bits &= ~0u >> (lo + 32 - c1);
-                    while (bits) {
-                        const int i = lo + __builtin_ctz(bits);
-                        bits &= bits - 1;
-                        acc ^= xs[(i + tid) & (MTJ_RING - 1)];
+                for (int w = head.first[r]; w < head.first[r + 1]; w += 8) {
+                    ConstList src = (ConstList)(uintptr_t)(lists + w);
+                    const uint32_t packed[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+                    uint32_t v[16];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t i0 = packed[k] & 0xffffu, i1 = packed[k] >> 16;
+                        // (a padding entry reads some word and drops it)
+                        v[2 * k] = xs[(i0 + tid) & (MTJ_RING - 1)] & (i0 == MTJ_NONE ? 0u : ~0u);
+                        v[2 * k + 1] = xs[(i1 + tid) & (MTJ_RING - 1)] & (i1 == MTJ_NONE ? 0u : ~0u);
                     }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc ^= v[k];
                 }
             }
             __syncthreads();   // the next round overwrites ring slots this round read
