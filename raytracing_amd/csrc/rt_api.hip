@@ -967,7 +967,7 @@ int rt_upload_samples(RtContext* ctx, int64_t dst_offset, const double* u, int64
     if (ctx->pack_E > 0) {
         const int64_t blocks = std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB);
         hipLaunchKernelGGL((k_pack<UploadedStream>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(),
-                           UploadedStream{ctx->staging.p}, dst_offset, n);
+                           UploadedStream{ctx->staging.p}, dst_offset, n, 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller
@@ -994,7 +994,7 @@ int rt_upload_samples_noalloc(RtContext* ctx, int64_t dst_offset, const double* 
     if (ctx->pack_E > 0) {
         const int64_t blocks = std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB);
         hipLaunchKernelGGL((k_pack<UploadedStream>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(),
-                           UploadedStream{staging}, dst_offset, n);
+                           UploadedStream{staging}, dst_offset, n, 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller, the array by the next call
@@ -1168,6 +1168,7 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     if (fused)
         hipLaunchKernelGGL(k_mt_emit, dim3(T), dim3(256), 0, ctx->stream, D, ctx->mt_ring.p, ctx->mt_end.p, ell, (long long)pos, total, next,
                            last_stream, (block + 1) * MT_N, ctx->emit_blocks.p, getenv("RT_EMIT_GENERATE_ONLY") ? -1 : n_emit_blocks, ctx->hit_mask.p, ctx->hit_pref.p);
+    bool points_made = false;
     for (int t0 = 0; t0 < T && !fused; t0 += per_pass) {
         const int n_streams = std::min(per_pass, T - t0);
         const long long w_lo = (long long)t0 << ell;                                   // origin of the pass's buffer
@@ -1179,9 +1180,13 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         // (a value that straddles two passes is whole in the earlier one: it reaches two words further)
         const long long p_lo = w_first <= pos ? 0 : (w_first - pos + 1) / 2;
         const long long p_hi = (w_hi - 2 - pos) / 2;                                   // inclusive
-        if (ctx->pack_E > 0 && p_hi >= p_lo && w_hi - 2 - pos >= 0)
+        // one pass over the whole stream: the float32 pass's disk points are made along the way
+        const bool with_points = per_pass >= T && p_lo == 0 && p_hi + 1 == total && ctx->have_packed32 && ctx->precision != RT_PRECISION_F64;
+        if (ctx->pack_E > 0 && p_hi >= p_lo && w_hi - 2 - pos >= 0) {
             hipLaunchKernelGGL((k_pack<GeneratedStream>), dim3((unsigned)pack_blocks), dim3(BLOCK), 0, ctx->stream, D,
-                               GeneratedStream{ctx->mt_raw.p + (pos + 2 * p_lo - w_lo)}, (int64_t)p_lo, (int64_t)(p_hi - p_lo + 1));
+                               GeneratedStream{ctx->mt_raw.p + (pos + 2 * p_lo - w_lo)}, (int64_t)p_lo, (int64_t)(p_hi - p_lo + 1), with_points ? 1 : 0);
+            if (with_points) points_made = true;
+        }
     }
     HIP_TRY(hipGetLastError());
     // the block may begin in the stream before the last one
@@ -1199,6 +1204,7 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     }
     *pos_out = (int32_t)(next - block * MT_N);
     ctx->samples_delivered = ctx->sample_total;   // the whole stream of this context has been made
+    ctx->disk_points_ready = points_made;
     // The raw words are only needed while they are being packed, but getting device memory back that
     // some process has used before takes the driver tens of milliseconds per GB (measured: 1.3 s for
     // the 50 GB of a 4K example_4 frame, every call), so a buffer of moderate size stays with the context.

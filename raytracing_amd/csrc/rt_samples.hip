@@ -38,17 +38,78 @@ struct GeneratedStream {
     }
 };
 
+// The point of the unit disk a pair of uniforms selects, as the float32 sample pass reads it
+// (reference objects.py:132-135): (sqrt(u_radius) cos(2 pi u_angle), sqrt(u_radius) sin(2 pi u_angle)),
+// evaluated in float64 and rounded to float.
+__device__ __forceinline__ void disk_point(double u_angle, double u_radius, float& x, float& y) {
+    double sn, cs;
+    sincospi(2.0 * u_angle, &sn, &cs);
+    const double rad = sqrt(u_radius);
+    x = (float)(rad * cs);
+    y = (float)(rad * sn);
+}
+
+// with_points (the piece [a, a + n) is the whole stream and the scene's samples go through the float32
+// pass): the entry's disk points are made here as well, from the values just read, and k_disk_points
+// need not read the packed uniforms again.
 template <typename Stream>
-__global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, int64_t n) {
+__global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, int64_t n, int with_points) {
     const SceneConst& sc = *D.sc;
     const int64_t b = a + n;
     const int64_t E = D.pack_E;
-    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (int64_t)gridDim.x * BLOCK) {
+    const int64_t E_points = with_points ? ((E + TILE - 1) / TILE) * TILE : E;   // the last tile's unused slots hold the disk's centre
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < E_points; e += (int64_t)gridDim.x * BLOCK) {
+        if (e >= E) {
+            for (int l = 0; l < D.n_lights; ++l) {
+                if (sc.lights[l].kind == RT_LIGHT_POINT) continue;
+                const int NP = (sc.lights[l].n_points + 1) >> 1;
+                float4* points = reinterpret_cast<float4*>(D.packed32) + D.pack32_base[l] + (e / TILE) * NP * TILE + (e % TILE);
+                for (int p = 0; p < NP; ++p) points[(int64_t)p * TILE] = make_float4(0, 0, 0, 0);
+            }
+            continue;
+        }
         const uint32_t info = D.info[D.list_ray[e]];
         const int node = D.list_node[e];
         for (int l = 0; l < D.n_lights; ++l) {
             const RtLight& Lt = sc.lights[l];
             if (Lt.kind == RT_LIGHT_POINT) continue;
+            if (with_points) {
+                // both uniforms of a sample together: packed as below, and the point they select
+                const int N = Lt.n_points, NP = (N + 1) >> 1;
+                float4* points = reinterpret_cast<float4*>(D.packed32) + D.pack32_base[l] + (e / TILE) * NP * TILE + (e % TILE);
+                int64_t h, jj;
+                bool lit = true;
+                if (Lt.kind == RT_LIGHT_SPOT) {
+                    lit = (info >> (I_BEAM_SHIFT + l)) & 1u;
+                    h = D.node_beam[node * RT_MAX_LIGHTS + l];
+                    jj = D.list_j[1 + l][e];
+                } else {
+                    h = D.node_hits[node];
+                    jj = D.list_j[0][e];
+                }
+                int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
+                if (Stream::WHOLE_IMAGE && D.sample_global) {
+                    const size_t KL = (size_t)D.K * RT_MAX_LIGHTS, at = (size_t)node * RT_MAX_LIGHTS + l;
+                    off = D.sample_global[at];
+                    h = D.sample_global[KL + at];
+                    jj += D.sample_global[2 * KL + at];
+                }
+                lit = lit && off >= 0;
+                double* dst = D.packed + D.pack_base[l] + e;
+                for (int p = 0; p < NP; ++p) {
+                    float x[2] = {0, 0}, y[2] = {0, 0};
+                    for (int k = 0; k < 2; ++k) {
+                        const int s = 2 * p + k;
+                        if (s >= N || !lit) break;
+                        const double u_angle = chunk(off + s * h + jj - a), u_radius = chunk(off + (int64_t)N * h + s * h + jj - a);
+                        dst[s * E] = u_angle;
+                        dst[D.pack_plane + s * E] = u_radius;
+                        disk_point(u_angle, u_radius, x[k], y[k]);
+                    }
+                    points[(int64_t)p * TILE] = make_float4(x[0], x[1], y[0], y[1]);
+                }
+                continue;
+            }
             int64_t h, jj;
             if (Lt.kind == RT_LIGHT_SPOT) {
                 if (!((info >> (I_BEAM_SHIFT + l)) & 1u)) continue;
@@ -106,12 +167,7 @@ __global__ __launch_bounds__(BLOCK) void k_disk_points(const double* __restrict_
             for (int k = 0; k < 2; ++k) {
                 const int s = 2 * p + k;
                 if (s >= N) break;
-                const double u_angle = angles[s * E + e], u_radius = angles[plane + s * E + e];
-                double sn, cs;
-                sincospi(2.0 * u_angle, &sn, &cs);
-                const double rad = sqrt(u_radius);
-                x[k] = (float)(rad * cs);
-                y[k] = (float)(rad * sn);
+                disk_point(angles[s * E + e], angles[plane + s * E + e], x[k], y[k]);
             }
         }
         points[i] = make_float4(x[0], x[1], y[0], y[1]);
@@ -493,12 +549,13 @@ __global__ __launch_bounds__(256) void k_mt_emit(Dev D, uint32_t* rings, long lo
 // s[i + j], s the sequence generated from the current window.  The low 31 bits of the new window's
 // first word are not meaningful (nothing reads them: the previous stream delivers that word, and the
 // recurrence itself only uses the top bit of a window's first word, so such a window can be moved
-// on again).  polys: [n_polys][624] coefficient words, polys[b] = x^(L 2^b) mod phi.
+// on again).  Polynomial b is x^(L 2^b) mod phi, L = 2^ell words per stream; heads[b] and `lists`
+// hold it as the list of its set coefficients (JumpPoly below).
 //
 // The windows are made level by level, one launch per level b = 0, 1, ...: workgroup blockIdx.x of
 // level b makes the window of stream t = 2^b + blockIdx.x from the window of stream t - 2^b (stream
 // 0: the caller's key block in ring 0, which must not have generated yet) with the one polynomial
-// polys[b] - one application per stream instead of one per set bit of t.
+// b - one application per stream instead of one per set bit of t.
 constexpr int MTJ_RING = 4096, MTJ_CHUNK = 8 * MT_STEP;   // coefficients consumed per round
 constexpr int MTJ_ROUNDS = (19937 + MTJ_CHUNK - 1) / MTJ_CHUNK;
 // A polynomial as the list of its set coefficients (what k_mt_jump walks; pulling them out of the
