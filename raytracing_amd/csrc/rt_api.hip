@@ -214,6 +214,7 @@ struct RtContext {
     hipEvent_t bounce_done[2] = {nullptr, nullptr};
     DevBuf<uint32_t> mt_ring, mt_raw, mt_polys;
     DevBuf<long long> mt_end;
+    DevBuf<unsigned long long> mt_need;     // store map of the generator (k_store_map)
     uint8_t* user_image8 = nullptr;
     int32_t* user_batches = nullptr;
     const int32_t* batch_guess = nullptr;
@@ -1030,9 +1031,12 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     // Absolute word indices: x[0..624) is the caller's key block, the first output consumed is
     // x[pos], the first one not consumed x[next].
     const long long next = (long long)pos + 2 * total;
-    // streams of L = 2^ell words, at most ~1024 of them
+    // streams of L = 2^ell words, at most 2048 of them: eight workgroups of k_mt_generate to a compute unit
+    // (4K example_4, 12.5e9 words: 1490 streams 9.1 ms + 4.1 ms of jumps; 745: 11.7 + 3.3; 2980: 8.1 + 5.7)
     int ell = 16;
-    while (((next + (1ll << ell) - 1) >> ell) > 1024) ++ell;
+    long long max_streams = 2048;
+    if (const char* e = getenv("RT_MT_MAX_STREAMS")) max_streams = std::max(1ll, atoll(e));
+    while (((next + (1ll << ell) - 1) >> ell) > max_streams) ++ell;
     const long long L = 1ll << ell;
     const int T = (int)((next + L - 1) >> ell);
     // words held in memory at a time (whole streams): all of them if a good part of the free device
@@ -1054,8 +1058,10 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     // memory).  Default: raw words first, k_pack afterwards.
     bool fused = false;
     if (const char* e = getenv("RT_MT_FUSED")) fused = e[0] == '1' && ctx->spot_mask == 0 && ctx->disk_lights && ctx->pack_E > 0;
+    // Default path: raw words nobody will read are not stored (k_store_map; RT_MT_STORE_ALL=1 stores all).
+    bool mapped = !fused && ctx->pack_E > 0 && !getenv("RT_MT_STORE_ALL");
     int n_emit_blocks = 0;
-    if (fused) {
+    if (fused || mapped) {
         const int K = ctx->tree.n_nodes(), Lv = ctx->tree.n_levels();
         std::vector<int32_t> hits(K), shade_base(Lv + 1);
         std::vector<uint32_t> pre((size_t)K * NCNT);
@@ -1070,16 +1076,25 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         const size_t KL = (size_t)K * RT_MAX_LIGHTS;
         for (int k = 0; k < K; ++k)
             for (int l = 0; l < ctx->sc_host.n_lights; ++l) {
-                if (ctx->sc_host.lights[l].kind != RT_LIGHT_DISK) continue;
                 const size_t at = (size_t)k * RT_MAX_LIGHTS + l;
                 const int64_t off = whole ? ctx->sample_global_host[at] : ctx->sample_off_host[at];
+                if (ctx->sc_host.lights[l].kind == RT_LIGHT_SPOT && mapped && off >= 0) {
+                    // values in the beam's own numbering: every word of the block is stored (its end: the next block's offset)
+                    EmitBlock b{};
+                    b.off = off;
+                    b.end = -1;
+                    b.light = EMIT_ALWAYS;
+                    blocks.push_back(b);
+                    continue;
+                }
+                if (ctx->sc_host.lights[l].kind != RT_LIGHT_DISK) continue;
                 const int64_t h = whole ? ctx->sample_global_host[KL + at] : hits[k];
-                if (off < 0 || h <= 0 || hits[k] <= 0) continue;
+                if (off < 0 || h <= 0 || (fused && hits[k] <= 0)) continue;
                 // shaded hits of the node: the level-wide running count at the next node's first tile minus its own
                 const int lv = ctx->tree.level[k];
                 const uint32_t upto = k + 1 < ctx->tree.level_start[lv + 1] ? pre[(size_t)(k + 1) * NCNT + C_SHADE]
                                                                              : (uint32_t)(shade_base[lv + 1] - shade_base[lv]);
-                if (upto == pre[(size_t)k * NCNT + C_SHADE]) continue;   // none: nobody reads this node's samples
+                if (fused && upto == pre[(size_t)k * NCNT + C_SHADE]) continue;   // none: nobody reads this node's samples
                 EmitBlock b{};
                 b.off = off;
                 b.rows = (uint32_t)ctx->sc_host.lights[l].n_points;
@@ -1095,13 +1110,16 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
             }
         std::sort(blocks.begin(), blocks.end(), [](const EmitBlock& a, const EmitBlock& b) { return a.off < b.off; });
         n_emit_blocks = (int)blocks.size();
-        fused = n_emit_blocks > 0;
-        if (fused) {
+        for (int i = 0; i < n_emit_blocks; ++i)
+            if (blocks[i].light == EMIT_ALWAYS) blocks[i].end = i + 1 < n_emit_blocks ? blocks[i + 1].off : (int64_t)total;
+        fused = fused && n_emit_blocks > 0;
+        mapped = mapped && n_emit_blocks > 0;
+        if (fused || mapped) {
             ctx->hit_mask.transient = ctx->hit_pref.transient = true;
             HIP_TRY(ctx->hit_word0.ensure(word0.size()));
             HIP_TRY(ctx->emit_blocks.ensure(blocks.size()));
             HIP_TRY(ctx->hit_mask.ensure((size_t)word0[K] + 2));
-            HIP_TRY(ctx->hit_pref.ensure((size_t)word0[K] + 2));
+            if (fused) HIP_TRY(ctx->hit_pref.ensure((size_t)word0[K] + 2));
             HIP_TRY(hipMemcpyAsync(ctx->hit_word0.p, word0.data(), word0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(hipMemcpyAsync(ctx->emit_blocks.p, blocks.data(), blocks.size() * sizeof(EmitBlock), hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(hipMemsetAsync(ctx->hit_mask.p, 0, ((size_t)word0[K] + 2) * 8, ctx->stream));
@@ -1109,7 +1127,7 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
             const Dev Dm = ctx->dev();
             for (int level = 0; level < Lv; ++level)
                 hipLaunchKernelGGL(k_hitmask, dim3(ctx->nb), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, Dm, level, ctx->hit_word0.p, ctx->hit_mask.p);
-            hipLaunchKernelGGL(k_hitprefix, dim3(K), dim3(BLOCK), 0, ctx->stream, ctx->hit_mask.p, ctx->hit_word0.p, ctx->hit_pref.p);
+            if (fused) hipLaunchKernelGGL(k_hitprefix, dim3(K), dim3(BLOCK), 0, ctx->stream, ctx->hit_mask.p, ctx->hit_word0.p, ctx->hit_pref.p);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1168,6 +1186,16 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     if (fused)
         hipLaunchKernelGGL(k_mt_emit, dim3(T), dim3(256), 0, ctx->stream, D, ctx->mt_ring.p, ctx->mt_end.p, ell, (long long)pos, total, next,
                            last_stream, (block + 1) * MT_N, ctx->emit_blocks.p, getenv("RT_EMIT_GENERATE_ONLY") ? -1 : n_emit_blocks, ctx->hit_mask.p, ctx->hit_pref.p);
+    // steps (227 words) a stream makes after its window, and the map's bytes for them
+    const int steps_per_stream = 2 * (int)((L + 2 - MT_N + 2 * MT_STEP - 1) / (2 * MT_STEP));
+    const int need_words = (steps_per_stream + 8 * MAP_GROUP - 1) / (8 * MAP_GROUP) * MAP_GROUP;
+    if (mapped) {
+        const long long n_bytes = (long long)T * need_words * 8;
+        ctx->mt_need.transient = true;
+        HIP_TRY(ctx->mt_need.ensure((size_t)T * need_words));
+        hipLaunchKernelGGL(k_store_map, dim3((unsigned)((n_bytes + 255) / 256)), dim3(256), 0, ctx->stream, ctx->emit_blocks.p, n_emit_blocks, ctx->hit_mask.p,
+                           (long long)pos, total, ell, steps_per_stream, need_words * 8, n_bytes, reinterpret_cast<uint8_t*>(ctx->mt_need.p));
+    }
     bool points_made = false;
     for (int t0 = 0; t0 < T && !fused; t0 += per_pass) {
         const int n_streams = std::min(per_pass, T - t0);
@@ -1175,7 +1203,7 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         const long long w_first = w_lo + (t0 > 0 ? 1 : 0);                             // first word the pass delivers
         const long long w_hi = std::min(((long long)(t0 + n_streams) << ell) + 2, next); // one past its last word
         hipLaunchKernelGGL(k_mt_generate, dim3(n_streams), dim3(256), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, ctx->mt_raw.p,
-                           t0, ell, w_lo, w_hi, last_stream, (block + 1) * MT_N);
+                           t0, ell, w_lo, w_hi, last_stream, (block + 1) * MT_N, mapped ? ctx->mt_need.p : nullptr, need_words);
         // values whose two words both lie in [w_first, w_hi): value p uses words pos + 2p, pos + 2p + 1
         // (a value that straddles two passes is whole in the earlier one: it reaches two words further)
         const long long p_lo = w_first <= pos ? 0 : (w_first - pos + 1) / 2;
@@ -1215,7 +1243,7 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
 int rt_trim(RtContext* ctx) {
     if (int rc = use_device(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->mt_raw.release(); ctx->mt_ring.release(); ctx->mt_end.release(); ctx->mt_polys.release();
+    ctx->mt_raw.release(); ctx->mt_ring.release(); ctx->mt_end.release(); ctx->mt_polys.release(); ctx->mt_need.release();
     ctx->staging.release(); ctx->hit_mask.release(); ctx->hit_pref.release(); ctx->hit_word0.release(); ctx->emit_blocks.release();
     return RT_OK;
 }

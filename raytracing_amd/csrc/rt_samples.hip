@@ -192,6 +192,7 @@ __global__ __launch_bounds__(BLOCK) void k_disk_points(const double* __restrict_
 // [0, L + 1]: two words of overlap, so that a value built from the last word of one stream and
 // the first of the next is whole in one of them.
 constexpr int MT_N = 624, MT_M = 397, MT_STEP = MT_N - MT_M, MT_RING = 2048;
+constexpr int MAP_GROUP = 4;   // 64-bit words of the store map k_mt_generate reads at a time
 __device__ __forceinline__ uint32_t mt_twist(uint32_t lo, uint32_t hi) {
     const uint32_t y = (lo & 0x80000000u) | (hi & 0x7fffffffu);
     return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
@@ -199,14 +200,20 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t lo, uint32_t hi) {
 // grid: one workgroup per stream t = t0 + blockIdx.x.
 //   raw[w - raw_origin] receives x[w] for the stream's words below w_end
 //   the stream with index last_stream keeps generating until its counter reaches gen_until
+//   need (or null: every word is stored): the store map k_store_map made - most of the time goes into
+//   the stores (the recurrence itself is a few instructions per word), and words nobody will read
+//   are not stored.  Only valid for a stream that has not generated yet (its counter at t L + 624).
 __global__ __launch_bounds__(256) void k_mt_generate(uint32_t* rings, long long* gen_ends, uint32_t* raw, int t0, int ell,
                                                      long long raw_origin, long long w_end, int last_stream,
-                                                     long long gen_until) {
-    __shared__ uint32_t ring[MT_RING];
+                                                     long long gen_until, const unsigned long long* __restrict__ need, int need_words) {
+    // x[n] at slot n & 2047 and again 2048 slots further up: a lane reads its four twist operands at
+    // fixed distances from one address that never has to wrap
+    __shared__ uint32_t ring[2 * MT_RING];
+    typedef const __attribute__((address_space(4))) unsigned long long* ConstMap;   // uniform reads through the scalar unit
     const int tid = threadIdx.x;
     const int t = t0 + blockIdx.x;
     uint32_t* ring_g = rings + (size_t)t * MT_RING;
-    for (int i = tid; i < MT_RING; i += 256) ring[i] = ring_g[i];
+    for (int i = tid; i < MT_RING; i += 256) ring[i] = ring[i + MT_RING] = ring_g[i];
     const long long g0 = gen_ends[t];
     const long long raw_first = ((long long)t << ell) + (t > 0 ? 1 : 0);
     long long raw_end = ((long long)(t + 1) << ell) + 2;
@@ -219,32 +226,54 @@ __global__ __launch_bounds__(256) void k_mt_generate(uint32_t* rings, long long*
     __syncthreads();
     // words of the window that exist already
     for (long long n = raw_first + tid; n < raw_end && n < g0; n += 256) out[n - raw_first] = ring[n & (MT_RING - 1)];
-    // two steps per iteration (all four twist operands were written before the previous
-    // barrier); positions as 32-bit offsets from g0
+    // two steps per iteration (all four twist operands were written before the previous barrier)
     const long long todo = target > g0 ? target - g0 : 0;
     const int iters = (int)((todo + 2 * MT_STEP - 1) / (2 * MT_STEP));
     const bool lane_on = tid < MT_STEP;
-    const int base = (int)(g0 & (MT_RING - 1));
+    int base = (int)(g0 & (MT_RING - 1));                 // slot of the iteration's first word (uniform)
     uint32_t prev = lane_on ? ring[(base + tid - MT_STEP) & (MT_RING - 1)] : 0u;
-    // raw index of this lane's word in step 0, relative to the window (may be negative)
-    long long rel = g0 + tid - raw_first;
-    int slot = (base + tid) & (MT_RING - 1);
-    for (int it = 0; it < iters; ++it) {
+    const long long rel_first = g0 - raw_first;           // place of iteration 0's first word in out[] (may be negative)
+    // iterations all of whose words have a place in out[]: [full_lo, full_hi)
+    const int full_lo = rel_first >= 0 ? 0 : (int)min((long long)iters, (-rel_first + 2 * MT_STEP - 1) / (2 * MT_STEP));
+    const int full_hi = raw_n > rel_first ? (int)min((long long)iters, (raw_n - rel_first) / (2 * MT_STEP)) : 0;
+    // store map: one byte per step (two per iteration), bit w of it = wave w stores; MAP_GROUP 64-bit
+    // words - four iterations each - are read at a time
+    ConstMap need_t = need ? (ConstMap)(uintptr_t)(need + (size_t)t * need_words) : nullptr;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t* lane_ring = ring + tid;
+    uint32_t* out_it = out + rel_first;                   // the iteration's first word in out[] (uniform)
+    auto iteration = [&](int it, unsigned both) {
         if (lane_on) {
-            const int s0 = slot, s1 = (slot + MT_STEP) & (MT_RING - 1);
-            const uint32_t lo0 = ring[(s0 - MT_N) & (MT_RING - 1)], hi0 = ring[(s0 - MT_N + 1) & (MT_RING - 1)];
-            const uint32_t lo1 = ring[(s1 - MT_N) & (MT_RING - 1)], hi1 = ring[(s1 - MT_N + 1) & (MT_RING - 1)];
+            const uint32_t* operands = lane_ring + ((base - MT_N) & (MT_RING - 1));
+            const uint32_t lo0 = operands[0], hi0 = operands[1], lo1 = operands[MT_STEP], hi1 = operands[MT_STEP + 1];
             const uint32_t x0 = prev ^ mt_twist(lo0, hi0);
             const uint32_t x1 = x0 ^ mt_twist(lo1, hi1);
-            ring[s0] = x0;
-            ring[s1] = x1;
-            if (rel >= 0 && rel < raw_n) out[rel] = x0;
-            if (rel + MT_STEP >= 0 && rel + MT_STEP < raw_n) out[rel + MT_STEP] = x1;
+            const int s0 = (base + tid) & (MT_RING - 1), s1 = (base + tid + MT_STEP) & (MT_RING - 1);
+            ring[s0] = x0; ring[s0 + MT_RING] = x0;
+            ring[s1] = x1; ring[s1 + MT_RING] = x1;
+            if (it >= full_lo && it < full_hi) {
+                if (both & 1u) out_it[tid] = x0;
+                if (both & 0x100u) out_it[tid + MT_STEP] = x1;
+            } else {
+                const long long rel = rel_first + (long long)it * (2 * MT_STEP) + tid;
+                if ((both & 1u) && rel >= 0 && rel < raw_n) out[rel] = x0;
+                if ((both & 0x100u) && rel + MT_STEP >= 0 && rel + MT_STEP < raw_n) out[rel + MT_STEP] = x1;
+            }
             prev = x1;
         }
-        slot = (slot + 2 * MT_STEP) & (MT_RING - 1);
-        rel += 2 * MT_STEP;
+        base = (base + 2 * MT_STEP) & (MT_RING - 1);
+        out_it += 2 * MT_STEP;
         __syncthreads();
+    };
+    for (int it0 = 0; it0 < iters; it0 += 4 * MAP_GROUP) {
+        unsigned long long map[MAP_GROUP];
+#pragma unroll
+        for (int q = 0; q < MAP_GROUP; ++q) map[q] = need_t ? need_t[min(it0 / 4 + q, need_words - 1)] : ~0ull;
+#pragma unroll
+        for (int q = 0; q < MAP_GROUP; ++q) {
+            const int n = min(4, iters - it0 - 4 * q);
+            for (int r = 0; r < n; ++r) iteration(it0 + 4 * q + r, (unsigned)(map[q] >> (r * 16 + wave)));
+        }
     }
     for (int i = tid; i < MT_RING; i += 256) ring_g[i] = ring[i];
     if (tid == 0) gen_ends[t] = g0 + (long long)iters * 2 * MT_STEP;
@@ -343,6 +372,76 @@ __global__ __launch_bounds__(BLOCK) void k_hitprefix(const unsigned long long* _
         if (tid == BLOCK - 1) s_carry = before + incl;
         __syncthreads();
     }
+}
+
+// Store map of k_mt_generate: which of the words it makes does k_pack read?  Only those of values
+// that belong to a shaded hit of this context - a third of the stream in the example scenes, and in
+// runs, since hits are numbered in pixel order and surfaces without a diffuse part cover areas.  The
+// generator stores a step's 227 words wave by wave (64 + 64 + 64 + 35); the map has one byte per step,
+// bit w set if wave w's words hold part of a value somebody reads (conservative: whenever that is
+// not cheap to tell - a run of values across two (node, light) blocks, a spotlight's block - the bit is
+// set).  One thread per step; steps are counted from word t L + 624 of stream t, where an unused
+// stream starts generating.
+//   blocks   every (node, light) block with values, sorted by offset; light == EMIT_ALWAYS: no mask
+//   need     [streams][bytes_per_stream] bytes (bytes_per_stream a multiple of 8)
+constexpr uint32_t EMIT_ALWAYS = 0xFFFFFFFFu;
+__device__ __forceinline__ bool any_mask_bits(const unsigned long long* __restrict__ mask, unsigned long long lo, unsigned long long hi) {
+    // bits [lo, hi), hi > lo
+    const unsigned long long w0 = lo >> 6, w1 = (hi - 1) >> 6;
+    for (unsigned long long w = w0; w <= w1; ++w) {
+        unsigned long long m = mask[w];
+        if (w == w0) m &= ~0ull << (lo & 63);
+        if (w == w1 && (hi & 63)) m &= (1ull << (hi & 63)) - 1;
+        if (m) return true;
+    }
+    return false;
+}
+__global__ __launch_bounds__(256) void k_store_map(const EmitBlock* __restrict__ blocks, int n_blocks, const unsigned long long* __restrict__ mask,
+                                                   long long pos, long long n_values, int ell, int steps_per_stream, int bytes_per_stream,
+                                                   long long n_bytes, uint8_t* __restrict__ need) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_bytes) return;
+    const long long t = i / bytes_per_stream;
+    const int step = (int)(i - t * bytes_per_stream);
+    if (step >= steps_per_stream) { need[i] = 0; return; }
+    const long long w_first = (t << ell) + MT_N + (long long)step * MT_STEP;
+    // the values with a word in [w_first, w_first + 227)
+    long long v_first = w_first >= pos ? (w_first - pos) >> 1 : 0;
+    long long v_last = w_first + MT_STEP - 1 >= pos ? (w_first + MT_STEP - 1 - pos) >> 1 : -1;
+    if (v_last > n_values - 1) v_last = n_values - 1;
+    if (v_first > v_last) { need[i] = 0; return; }
+    // block of the first value: the last one that begins at or before it
+    int lo = 0, hi = n_blocks - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blocks[mid].off <= v_first) lo = mid; else hi = mid - 1;
+    }
+    const EmitBlock B = blocks[lo];
+    if (B.light == EMIT_ALWAYS || v_first < B.off || v_last >= B.end) { need[i] = 0xF; return; }
+    unsigned bits = 0;
+    for (int w = 0; w < 4; ++w) {
+        const long long wa = w_first + 64 * w, wb = wa + (w == 3 ? MT_STEP - 192 : 64);   // [wa, wb)
+        if (wb <= pos) continue;
+        const long long va = wa >= pos ? (wa - pos) >> 1 : 0;
+        const long long vb = min((wb - 1 - pos) >> 1, n_values - 1);
+        if (va > vb) continue;
+        const long long n = vb - va + 1;
+        if (n >= (long long)B.h) { bits |= 1u << w; continue; }
+        const long long rel = va - B.off;
+        long long row = (long long)((double)rel * B.inv_h);
+        long long col = rel - row * (long long)B.h;
+        if (col < 0) col += B.h; else if (col >= (long long)B.h) col -= B.h;
+        // columns [col, col + n), the part beyond h on the next row from column 0
+        bool any = false;
+        for (int part = 0; part < 2 && !any; ++part) {
+            long long c0 = part == 0 ? col : 0, c1 = part == 0 ? min(col + n, (long long)B.h) : col + n - (long long)B.h;
+            c0 = max(c0, (long long)B.first_col) - B.first_col;
+            c1 = min(c1, (long long)B.first_col + B.mine) - B.first_col;
+            if (c0 < c1) any = any_mask_bits(mask, (unsigned long long)B.word0 * 64 + c0, (unsigned long long)B.word0 * 64 + c1);
+        }
+        if (any) bits |= 1u << w;
+    }
+    need[i] = (uint8_t)bits;
 }
 
 // grid: one workgroup per stream t = blockIdx.x (see k_mt_generate for rings, gen_ends, ell, last_stream,

@@ -58,6 +58,7 @@ class Comm:
         self.device = device          # torch device the backend's tensors must live on
         self.host_staged = False      # device tensors go through host copies (gloo)
         self.sharded = False          # the multi-rank path is taken (see is_sharded)
+        self._side = None
         if group is None:
             self.rank, self.world = 0, 1
         else:
@@ -75,13 +76,27 @@ class Comm:
         t = torch.from_numpy(np.ascontiguousarray(a))
         return t.to(self.device) if self.device is not None else t
 
+    def _aside(self):
+        """Stream context for exchanges that start and end on the host: a stream of this object's own,
+        which nobody ever captures into a graph.  (RCCL's watchdog thread polls the end event of every
+        collective until it has seen it finished; HIP refuses such a query while the stream the event
+        was recorded on is being captured, and the process aborts.)"""
+        import contextlib
+        if self.device is None:
+            return contextlib.nullcontext()
+        import torch
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        return torch.cuda.stream(self._side)
+
     def all_reduce_sum(self, a):
         if not self.sharded:
             return np.asarray(a)
         import torch.distributed as dist
-        t = self._t(a)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy()
+        with self._aside():
+            t = self._t(a)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t.cpu().numpy()
 
     def all_reduce_device(self, t):
         """In-place sum of a torch tensor over the ranks.  Device tensors with RCCL: queued behind
@@ -107,8 +122,9 @@ class Comm:
             self.tile_group = dist.new_group(ranks=ranks, backend=dist.get_backend(self.group))
             # set the communicator up now, with every rank taking part, not at the first transfer
             import torch
-            one = torch.zeros(1, dtype=torch.int32, device=self.device if self.device is not None else "cpu")
-            dist.all_reduce(one, group=self.tile_group)
+            with self._aside():
+                one = torch.zeros(1, dtype=torch.int32, device=self.device if self.device is not None else "cpu")
+                dist.all_reduce(one, group=self.tile_group)
 
     def all_gather(self, a):
         """Stack every rank's array (same shape everywhere) along a new first axis."""
@@ -117,15 +133,17 @@ class Comm:
             return a[None]
         import torch
         import torch.distributed as dist
-        t = self._t(a)
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(out, t, group=self.group)
-        return np.stack([o.cpu().numpy() for o in out])
+        with self._aside():
+            t = self._t(a)
+            out = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(out, t, group=self.group)
+            return np.stack([o.cpu().numpy() for o in out])
 
     def barrier(self):
         if self.sharded:
             import torch.distributed as dist
-            dist.barrier(group=self.group)
+            with self._aside():
+                dist.barrier(group=self.group)
 
     def gather_tiles(self, full, tile, bounds, width):
         """Point-to-point gather of row tiles into ``full`` on rank 0.  ``full`` and
@@ -745,6 +763,14 @@ class FrameSet:
         return g
 
     def capture(self):
+        if self.sharded:
+            # The collectives queued on these streams so far (the first geometry pass's sums) have
+            # finished, but RCCL's watchdog thread may not have looked at their end events yet - it
+            # does so every 100 ms - and HIP fails that look (and torch aborts the process) while the
+            # stream such an event was recorded on is capturing.  Give the watchdog time for its round.
+            import time
+            self.synchronize()
+            time.sleep(0.35)
         try:
             if not self.sharded:
                 if self.frame_pipelines:

@@ -483,6 +483,35 @@ def test_device_mt19937_streams_and_passes(monkeypatch, raw_words):
     assert dev_state[2] == host_state[2] and np.array_equal(dev_state[1], host_state[1])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("store_all,max_streams", [(False, None), (True, None), (False, 5), (False, 100000)])
+def test_device_mt19937_store_map(monkeypatch, store_all, max_streams):
+    """The generator leaves out the words of values no shaded hit reads (default) or stores them all;
+    few long streams or many short ones: the frame (mixed precision, disk points made along the way)
+    equals the one from host-drawn samples and the stream ends in the same place.  The spotlight's
+    blocks are not screened (in-beam numbering) and lie between screened ones."""
+    from raytracing_amd import objects
+    for name, value in (("RT_MT_STORE_ALL", "1" if store_all else None), ("RT_MT_MAX_STREAMS", max_streams)):
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, str(value))
+    spot_scene = synthetic.spotlight_scene("linear", 16, 200, 112)
+    spot_scene.light_sources = [objects.DiskSource(x=-3, y=1, z=6, radius=1.5, intensity=20, N=5)] + list(spot_scene.light_sources)
+    for scene in (build_scene("example_4", 480, 270), spot_scene):
+        np.random.seed(99)
+        st = np.random.get_state()
+        st = (st[0], st[1], 5) + tuple(st[3:])
+        images = {}
+        for sampler in ("host", "device"):
+            np.random.set_state(st)
+            with Renderer(scene, sampler=sampler) as r:
+                r.begin_rows(0, r.params.height)
+                images[sampler] = (r.render_pixels().copy(), np.random.get_state())
+        assert np.array_equal(images["host"][0], images["device"][0])
+        assert images["host"][1][2] == images["device"][1][2] and np.array_equal(images["host"][1][1], images["device"][1][1])
+
+
 # ---------------------------------------------------------------------------------------------
 # Degenerate scenes: nothing to hit, nothing that lights, no ambient term.
 @pytest.mark.gpu
