@@ -1169,11 +1169,13 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         HIP_TRY(ctx->mt_polys.ensure(polys.size()));
         HIP_TRY(hipMemcpy(ctx->mt_polys.p, polys.data(), polys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         const uint32_t* device_lists = ctx->mt_polys.p + head_words;
-        // level b: the windows of streams 2^b .. min(2^(b+1), T) - 1 from those of streams 0 .. (one polynomial each)
+        // level b: the windows of streams 2^b .. min(2^(b+1), T) - 1 from those of streams 0 .. (one polynomial each),
+        // summed into zeroed rings
+        HIP_TRY(hipMemsetAsync(ctx->mt_ring.p + MT_RING, 0, (size_t)(T - 1) * MT_RING * sizeof(uint32_t), ctx->stream));
         for (int b = 0; b < n_polys; ++b) {
             const int count = std::min(1 << b, T - (1 << b));
             if (count > 0)
-                hipLaunchKernelGGL(k_mt_jump, dim3(count), dim3(640), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p,
+                hipLaunchKernelGGL(k_mt_jump, dim3(count * MTJ_ROUNDS), dim3(640), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p,
                                    reinterpret_cast<const JumpPoly*>(ctx->mt_polys.p), device_lists, b, ell);
         }
     }

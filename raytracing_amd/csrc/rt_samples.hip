@@ -651,10 +651,13 @@ __global__ __launch_bounds__(256) void k_mt_emit(Dev D, uint32_t* rings, long lo
 // on again).  Polynomial b is x^(L 2^b) mod phi, L = 2^ell words per stream; heads[b] and `lists`
 // hold it as the list of its set coefficients (JumpPoly below).
 //
-// The windows are made level by level, one launch per level b = 0, 1, ...: workgroup blockIdx.x of
-// level b makes the window of stream t = 2^b + blockIdx.x from the window of stream t - 2^b (stream
-// 0: the caller's key block in ring 0, which must not have generated yet) with the one polynomial
-// b - one application per stream instead of one per set bit of t.
+// The windows are made level by level, one launch per level b = 0, 1, ...: the window of stream
+// t = 2^b + i comes from the window of stream t - 2^b (stream 0: the caller's key block in ring 0,
+// which must not have generated yet) with the one polynomial b - one application per stream instead
+// of one per set bit of t.  An application is shared by MTJ_ROUNDS workgroups (blockIdx.x =
+// i MTJ_ROUNDS + r): each takes the coefficients [r MTJ_CHUNK, (r + 1) MTJ_CHUNK) - it generates s
+// as far as they reach, which is cheap next to the sums - and adds its part into the stream's ring
+// with atomic XORs, so the rings of the streams 1.. must be zero before the first level.
 constexpr int MTJ_RING = 4096, MTJ_CHUNK = 8 * MT_STEP;   // coefficients consumed per round
 constexpr int MTJ_ROUNDS = (19937 + MTJ_CHUNK - 1) / MTJ_CHUNK;
 // A polynomial as the list of its set coefficients (what k_mt_jump walks; pulling them out of the
@@ -667,66 +670,57 @@ struct JumpPoly {
 };
 __global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen_ends, const JumpPoly* heads, const uint32_t* lists, int level, int ell) {
     __shared__ uint32_t xs[MTJ_RING];     // s[i] at slot i & 4095
-    __shared__ uint32_t win[MT_N];
     typedef const __attribute__((address_space(4))) uint32_t* ConstList;   // uniform reads through the scalar unit
     const int tid = threadIdx.x;
-    const int t = (1 << level) + blockIdx.x;
+    const int t = (1 << level) + blockIdx.x / MTJ_ROUNDS;
+    const int r = blockIdx.x % MTJ_ROUNDS;          // this workgroup's share of the polynomial
     const long long L = 1ll << ell;
     // the source window: x[u L .. u L + 623] of stream u = t - 2^level, in that stream's ring
     {
         const int u = t - (1 << level);
         const long long from = (long long)u * L;
-        for (int j = tid; j < MT_N; j += 640) win[j] = rings[(size_t)u * MT_RING + ((from + j) & (MT_RING - 1))];
+        for (int j = tid; j < MT_N; j += 640) xs[j] = rings[(size_t)u * MT_RING + ((from + j) & (MT_RING - 1))];
     }
     __syncthreads();
+    // s up to the last word the share reads: s[c0 + MTJ_CHUNK + 623] (the ring keeps the last 4096)
+    const int c0 = r * MTJ_CHUNK;
     {
-        for (int j = tid; j < MT_N; j += 640) xs[j] = win[j];
-        __syncthreads();
+        uint32_t prev = (tid < MT_STEP) ? xs[MT_N - MT_STEP + tid] : 0u;   // own-chain value s[gen - 227 + tid]
+        for (int gen = MT_N; gen < c0 + MTJ_CHUNK + MT_N; gen += 2 * MT_STEP) {
+            if (tid < MT_STEP) {
+                const int n0 = gen + tid, n1 = n0 + MT_STEP;
+                const uint32_t x0 = prev ^ mt_twist(xs[(n0 - MT_N) & (MTJ_RING - 1)], xs[(n0 - MT_N + 1) & (MTJ_RING - 1)]);
+                const uint32_t x1 = x0 ^ mt_twist(xs[(n1 - MT_N) & (MTJ_RING - 1)], xs[(n1 - MT_N + 1) & (MTJ_RING - 1)]);
+                xs[n0 & (MTJ_RING - 1)] = x0;
+                xs[n1 & (MTJ_RING - 1)] = x1;
+                prev = x1;
+            }
+            __syncthreads();
+        }
+    }
+    // the share's coefficients, sixteen at a time: their reads are in flight together
+    if (tid < MT_N) {
         const JumpPoly& head = heads[level];
         uint32_t acc = 0;
-        uint32_t prev = (tid < MT_STEP) ? xs[MT_N - MT_STEP + tid] : 0u;   // own-chain value s[gen - 227 + tid]
-        int gen = MT_N;                                                     // s[0 .. gen) exist
-        for (int r = 0; r < MTJ_ROUNDS; ++r) {
-            const int c0 = r * MTJ_CHUNK;
-            // make s available up to c0 + MTJ_CHUNK + 623
-            while (gen < c0 + MTJ_CHUNK + MT_N) {
-                if (tid < MT_STEP) {
-                    const int n0 = gen + tid, n1 = n0 + MT_STEP;
-                    const uint32_t x0 = prev ^ mt_twist(xs[(n0 - MT_N) & (MTJ_RING - 1)], xs[(n0 - MT_N + 1) & (MTJ_RING - 1)]);
-                    const uint32_t x1 = x0 ^ mt_twist(xs[(n1 - MT_N) & (MTJ_RING - 1)], xs[(n1 - MT_N + 1) & (MTJ_RING - 1)]);
-                    xs[n0 & (MTJ_RING - 1)] = x0;
-                    xs[n1 & (MTJ_RING - 1)] = x1;
-                    prev = x1;
-                }
-                gen += 2 * MT_STEP;
-                __syncthreads();
-            }
-            // accumulate this round's coefficients, sixteen at a time: their reads are in flight together
-            if (tid < MT_N) {
-                for (int w = head.first[r]; w < head.first[r + 1]; w += 8) {
-                    ConstList src = (ConstList)(uintptr_t)(lists + w);
-                    const uint32_t packed[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
-                    uint32_t v[16];
+        for (int w = head.first[r]; w < head.first[r + 1]; w += 8) {
+            ConstList src = (ConstList)(uintptr_t)(lists + w);
+            const uint32_t packed[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+            uint32_t v[16];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t i0 = packed[k] & 0xffffu, i1 = packed[k] >> 16;
-                        // (a padding entry reads some word and drops it)
-                        v[2 * k] = xs[(i0 + tid) & (MTJ_RING - 1)] & (i0 == MTJ_NONE ? 0u : ~0u);
-                        v[2 * k + 1] = xs[(i1 + tid) & (MTJ_RING - 1)] & (i1 == MTJ_NONE ? 0u : ~0u);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) acc ^= v[k];
-                }
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t i0 = packed[k] & 0xffffu, i1 = packed[k] >> 16;
+                // (a padding entry reads some word and drops it)
+                v[2 * k] = xs[(i0 + tid) & (MTJ_RING - 1)] & (i0 == MTJ_NONE ? 0u : ~0u);
+                v[2 * k + 1] = xs[(i1 + tid) & (MTJ_RING - 1)] & (i1 == MTJ_NONE ? 0u : ~0u);
             }
-            __syncthreads();   // the next round overwrites ring slots this round read
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc ^= v[k];
         }
-        if (tid < MT_N) win[tid] = acc;
-        __syncthreads();
+        // into the stream's ring (zero before the launch): window word j is x[t L + j]
+        const long long first = (long long)t * L;
+        if (acc) atomicXor(&rings[(size_t)t * MT_RING + ((first + tid) & (MT_RING - 1))], acc);
+        if (r == 0 && tid == 0) gen_ends[t] = first + MT_N;
     }
-    // the stream's ring: window word j is x[t L + j]
-    const long long first = (long long)t * L;
-    for (int j = tid; j < MT_N; j += 640) rings[(size_t)t * MT_RING + ((first + j) & (MT_RING - 1))] = win[j];
-    if (tid == 0) gen_ends[t] = first + MT_N;
 }
 
 }  // namespace rt
