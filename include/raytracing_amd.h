@@ -123,6 +123,9 @@ typedef struct RtCounters {
     int32_t overflow;        /* non-zero: arena too small, results invalid             */
     int32_t certify_mismatches; /* RT_PRECISION_MIXED_CHECKED only: certified float32 shadow
                                 decisions that differ from the float64 decision (must be 0) */
+    int64_t generator_words; /* last rt_generate_samples: 32-bit words of the stream it made ... */
+    int64_t generator_words_stored; /* ... and how many of them it stored for packing (the words
+                                of values that shaded hits of this context read, in runs of 64) */
 } RtCounters;
 
 /* Accumulated device time per kernel kind, filled when profiling is on. */
@@ -275,6 +278,7 @@ int rt_upload_samples_noalloc(RtContext *ctx, int64_t dst_offset, const double *
  * the stream) stays with the context between calls while it is at most 64 GB (RT_MT_RAW_KEEP_GB
  * in the environment; rt_trim releases it at once); longer streams, or ones that half of the free
  * device memory does not hold, are made in several passes through a buffer that is released again.
+ * Words of values that no shaded hit of this context reads are not stored in it (RT_MT_STORE_ALL=1: all are).
  * RT_MT_FUSED=1 (disk lights only): the values go straight to their places, no such buffer at all,
  * at about 1.6 times the kernel time. */
 int rt_set_sample_layout_global(RtContext *ctx, const int64_t *offsets, const int64_t *columns,

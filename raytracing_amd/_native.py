@@ -63,7 +63,8 @@ class RtCounters(C.Structure):
                 ("shaded_hits", C.c_int64), ("shaded_samples", C.c_int64), ("fallback_samples", C.c_int64),
                 ("stored_records", C.c_int64), ("live_hits", C.c_int64),
                 ("arena_rays_used", C.c_int64), ("arena_capacity", C.c_int64),
-                ("n_nodes", C.c_int32), ("n_levels", C.c_int32), ("overflow", C.c_int32), ("certify_mismatches", C.c_int32)]
+                ("n_nodes", C.c_int32), ("n_levels", C.c_int32), ("overflow", C.c_int32), ("certify_mismatches", C.c_int32),
+                ("generator_words", C.c_int64), ("generator_words_stored", C.c_int64)]
 
 
 class RtProfile(C.Structure):

@@ -215,6 +215,8 @@ struct RtContext {
     DevBuf<uint32_t> mt_ring, mt_raw, mt_polys;
     DevBuf<long long> mt_end;
     DevBuf<unsigned long long> mt_need;     // store map of the generator (k_store_map)
+    DevBuf<unsigned long long> mt_stat;
+    long long generator_words = 0, generator_words_stored = 0;   // of the last rt_generate_samples
     uint8_t* user_image8 = nullptr;
     int32_t* user_batches = nullptr;
     const int32_t* batch_guess = nullptr;
@@ -1195,8 +1197,10 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         const long long n_bytes = (long long)T * need_words * 8;
         ctx->mt_need.transient = true;
         HIP_TRY(ctx->mt_need.ensure((size_t)T * need_words));
+        HIP_TRY(ctx->mt_stat.ensure(1));
+        HIP_TRY(hipMemsetAsync(ctx->mt_stat.p, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k_store_map, dim3((unsigned)((n_bytes + 255) / 256)), dim3(256), 0, ctx->stream, ctx->emit_blocks.p, n_emit_blocks, ctx->hit_mask.p,
-                           (long long)pos, total, ell, steps_per_stream, need_words * 8, n_bytes, reinterpret_cast<uint8_t*>(ctx->mt_need.p));
+                           (long long)pos, total, ell, steps_per_stream, need_words * 8, n_bytes, reinterpret_cast<uint8_t*>(ctx->mt_need.p), ctx->mt_stat.p);
     }
     bool points_made = false;
     for (int t0 = 0; t0 < T && !fused; t0 += per_pass) {
@@ -1235,6 +1239,13 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     *pos_out = (int32_t)(next - block * MT_N);
     ctx->samples_delivered = ctx->sample_total;   // the whole stream of this context has been made
     ctx->disk_points_ready = points_made;
+    ctx->generator_words = next;
+    ctx->generator_words_stored = fused ? 0 : next;
+    if (mapped) {
+        unsigned long long kept = 0;
+        HIP_TRY(hipMemcpy(&kept, ctx->mt_stat.p, sizeof kept, hipMemcpyDeviceToHost));
+        ctx->generator_words_stored = (long long)kept + (long long)T * MT_N;   // and every stream's window
+    }
     // The raw words are only needed while they are being packed, but getting device memory back that
     // some process has used before takes the driver tens of milliseconds per GB (measured: 1.3 s for
     // the 50 GB of a 4K example_4 frame, every call), so a buffer of moderate size stays with the context.
@@ -1450,6 +1461,8 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     out->n_levels = Lv;
     out->overflow = flag;
     out->certify_mismatches = (int32_t)std::min<unsigned long long>(work[5], 0x7FFFFFFFull);
+    out->generator_words = ctx->generator_words;
+    out->generator_words_stored = ctx->generator_words_stored;
     return RT_OK;
 }
 

@@ -382,8 +382,9 @@ __global__ __launch_bounds__(BLOCK) void k_hitprefix(const unsigned long long* _
 // not cheap to tell - a run of values across two (node, light) blocks, a spotlight's block - the bit is
 // set).  One thread per step; steps are counted from word t L + 624 of stream t, where an unused
 // stream starts generating.
-//   blocks   every (node, light) block with values, sorted by offset; light == EMIT_ALWAYS: no mask
-//   need     [streams][bytes_per_stream] bytes (bytes_per_stream a multiple of 8)
+//   blocks      every (node, light) block with values, sorted by offset; light == EMIT_ALWAYS: no mask
+//   need        [streams][bytes_per_stream] bytes (bytes_per_stream a multiple of 8)
+//   words_kept  += the words the map lets the generator store
 constexpr uint32_t EMIT_ALWAYS = 0xFFFFFFFFu;
 __device__ __forceinline__ bool any_mask_bits(const unsigned long long* __restrict__ mask, unsigned long long lo, unsigned long long hi) {
     // bits [lo, hi), hi > lo
@@ -396,20 +397,18 @@ __device__ __forceinline__ bool any_mask_bits(const unsigned long long* __restri
     }
     return false;
 }
-__global__ __launch_bounds__(256) void k_store_map(const EmitBlock* __restrict__ blocks, int n_blocks, const unsigned long long* __restrict__ mask,
-                                                   long long pos, long long n_values, int ell, int steps_per_stream, int bytes_per_stream,
-                                                   long long n_bytes, uint8_t* __restrict__ need) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_bytes) return;
+// the byte of step i % bytes_per_stream of stream i / bytes_per_stream
+__device__ unsigned store_map_bits(const EmitBlock* __restrict__ blocks, int n_blocks, const unsigned long long* __restrict__ mask,
+                                   long long pos, long long n_values, int ell, int steps_per_stream, int bytes_per_stream, long long i) {
     const long long t = i / bytes_per_stream;
     const int step = (int)(i - t * bytes_per_stream);
-    if (step >= steps_per_stream) { need[i] = 0; return; }
+    if (step >= steps_per_stream) return 0;
     const long long w_first = (t << ell) + MT_N + (long long)step * MT_STEP;
     // the values with a word in [w_first, w_first + 227)
     long long v_first = w_first >= pos ? (w_first - pos) >> 1 : 0;
     long long v_last = w_first + MT_STEP - 1 >= pos ? (w_first + MT_STEP - 1 - pos) >> 1 : -1;
     if (v_last > n_values - 1) v_last = n_values - 1;
-    if (v_first > v_last) { need[i] = 0; return; }
+    if (v_first > v_last) return 0;
     // block of the first value: the last one that begins at or before it
     int lo = 0, hi = n_blocks - 1;
     while (lo < hi) {
@@ -417,7 +416,7 @@ __global__ __launch_bounds__(256) void k_store_map(const EmitBlock* __restrict__
         if (blocks[mid].off <= v_first) lo = mid; else hi = mid - 1;
     }
     const EmitBlock B = blocks[lo];
-    if (B.light == EMIT_ALWAYS || v_first < B.off || v_last >= B.end) { need[i] = 0xF; return; }
+    if (B.light == EMIT_ALWAYS || v_first < B.off || v_last >= B.end) return 0xF;
     unsigned bits = 0;
     for (int w = 0; w < 4; ++w) {
         const long long wa = w_first + 64 * w, wb = wa + (w == 3 ? MT_STEP - 192 : 64);   // [wa, wb)
@@ -441,7 +440,21 @@ __global__ __launch_bounds__(256) void k_store_map(const EmitBlock* __restrict__
         }
         if (any) bits |= 1u << w;
     }
-    need[i] = (uint8_t)bits;
+    return bits;
+}
+__global__ __launch_bounds__(256) void k_store_map(const EmitBlock* __restrict__ blocks, int n_blocks, const unsigned long long* __restrict__ mask,
+                                                   long long pos, long long n_values, int ell, int steps_per_stream, int bytes_per_stream,
+                                                   long long n_bytes, uint8_t* __restrict__ need, unsigned long long* __restrict__ words_kept) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    unsigned bits = 0;
+    if (i < n_bytes) {
+        bits = store_map_bits(blocks, n_blocks, mask, pos, n_values, ell, steps_per_stream, bytes_per_stream, i);
+        need[i] = (uint8_t)bits;
+    }
+    // statistics: words the generator will store (64 per wave, 35 for the fourth)
+    unsigned words = 64u * (unsigned)__popc(bits & 7u) + (unsigned)(MT_STEP - 192) * (bits >> 3);
+    for (int off = 32; off > 0; off >>= 1) words += __shfl_down(words, off);
+    if ((threadIdx.x & 63) == 0 && words) atomicAdd(words_kept, (unsigned long long)words);
 }
 
 // grid: one workgroup per stream t = blockIdx.x (see k_mt_generate for rings, gen_ends, ell, last_stream,

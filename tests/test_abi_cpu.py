@@ -33,7 +33,7 @@ def test_struct_sizes_match_the_header_layout():
     import ctypes as C
     assert C.sizeof(_native.RtLight) == 16 + 8 * (3 + 1 + 3 + 3 + 1 + 3 + 3 + 3 + 2)
     assert C.sizeof(_native.RtParams) == 24 + 8 * 5
-    assert C.sizeof(_native.RtCounters) == 10 * 8 + 4 * 4
+    assert C.sizeof(_native.RtCounters) == 10 * 8 + 4 * 4 + 2 * 8
     assert C.sizeof(_native.RtScene) == 8 + 3 * 8 + 8 * (5 * 3 + 4)
 
 

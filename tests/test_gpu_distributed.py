@@ -61,9 +61,12 @@ def _worker(rank, world, port, name, w, h, out_path, precision="mixed"):
             full[r0 * w:r1 * w] = tile
         comm.gather_tiles(full, tile, bounds, w)
         stats = r.global_stats()
+        c = ctx.counters()
+        generator = comm.all_gather(np.array([c["generator_words"], c["generator_words_stored"]], dtype=np.int64))
         comm.barrier()
         if rank == 0:
-            np.savez(out_path, image=full.numpy().reshape(h, w, 3), bounds=bounds, rays=stats["rays"], hits=stats["hits"])
+            np.savez(out_path, image=full.numpy().reshape(h, w, 3), bounds=bounds, rays=stats["rays"], hits=stats["hits"],
+                     generator=generator, total=total)
         ctx.close()
     finally:
         dist.destroy_process_group()
@@ -81,6 +84,31 @@ def test_two_ranks_on_one_gpu(tmp_path, name, precision, tol):
     r = g[name + "_rays"]
     assert int(res["rays"]) == int(r[r >= 3].sum())
     assert int(res["hits"]) == int(g[name + "_hits"].sum())
+
+
+def test_two_ranks_store_their_own_part_of_the_stream(tmp_path):
+    """Every rank runs the generator over the whole image's stream (the same final state everywhere) but
+    stores only the words of values its own shaded hits read: the memory traffic of the sample set-up
+    divides between the ranks, its arithmetic does not."""
+    from raytracing_amd.raytrace import Renderer
+    from raytracing_amd.Scenes.scenes import build_scene
+    w, h = 320, 180
+    out = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(2, _free_port(), "example_4", w, h, out, "mixed"), nprocs=2, join=True)
+    res = np.load(out)
+    np.random.seed(0)
+    with Renderer(build_scene("example_4", w, h)) as r:
+        r.begin_rows(0, h)
+        one = r.render_pixels().reshape(h, w, 3).copy()
+        alone = r.ctx.counters()
+    assert np.abs(res["image"] - one).max() <= 2e-5
+    words = 2 * int(res["total"])
+    assert alone["generator_words"] == words + 624        # the stream starts behind a fresh key block
+    for made, stored in res["generator"]:
+        assert made == alone["generator_words"]            # not divided
+        assert stored <= 0.6 * made
+        assert stored <= 0.75 * alone["generator_words_stored"]
+    assert res["generator"][:, 1].sum() <= 1.2 * alone["generator_words_stored"]
 
 
 def _worker_rgb8(rank, world, port, name, w, h, out_path):
