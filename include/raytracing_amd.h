@@ -279,6 +279,9 @@ int rt_upload_samples_noalloc(RtContext *ctx, int64_t dst_offset, const double *
  * in the environment; rt_trim releases it at once); longer streams, or ones that half of the free
  * device memory does not hold, are made in several passes through a buffer that is released again.
  * Words of values that no shaded hit of this context reads are not stored in it (RT_MT_STORE_ALL=1: all are).
+ * In mixed precision, with a buffer that stays, the samples are kept as the disk points of the float32 pass plus
+ * these raw words (the few float64 readers build their uniforms from them); rt_trim, an upload over generated
+ * samples and RT_PRECISION_MIXED_CHECKED unpack them into the float64 array first (RT_PACK_UNIFORMS=1: always).
  * RT_MT_FUSED=1 (disk lights only): the values go straight to their places, no such buffer at all,
  * at about 1.6 times the kernel time. */
 int rt_set_sample_layout_global(RtContext *ctx, const int64_t *offsets, const int64_t *columns,
@@ -308,7 +311,9 @@ int rt_build_light_map(const double *sphere_geom /* [n][4] */, int64_t n, const 
 
 /* Gives back the work buffers of the sample calls (the generator's raw words and stream states, the
  * staging buffer of rt_upload_samples): they are allocated again when next needed.  No counterpart in
- * the reference.  Waits for the context's stream. */
+ * the reference.  Waits for the context's stream.  Samples that live in the raw words are unpacked first
+ * (one more kernel; RT_ERR_STATE under stream capture), and launches of rt_shade recorded in a graph
+ * before the call stay valid. */
 int rt_trim(RtContext *ctx);
 
 /* Host only: the coefficients (bit i = coefficient of x^i, 624 words) of x^(2^k) mod the

@@ -154,6 +154,9 @@ struct RtContext {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // rt_generate_samples: the jump-ahead runs beside the hit mask and the store map
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
 
     bool have_scene = false, frame_begun = false, geometry_done = false, layout_set = false, shaded = false;
     int next_level = 0;
@@ -195,6 +198,12 @@ struct RtContext {
     DevBuf<float> packed32;
     bool have_packed32 = false;
     bool disk_points_ready = false;   // packed32 holds the disk points of the current contents of packed
+    // The generated samples exist as disk points (packed32) and as the generator's raw words, `packed` has not
+    // been filled: value i of the stream is made of the words mt_raw[raw_value0 + 2 i], + 1 (materialize_packed fills it)
+    bool samples_in_raw = false;
+    long long raw_value0 = 0;
+    DevBuf<const uint32_t*> raw_slot;          // what the kernels read: mt_raw + raw_value0, or null (Dev::raw_values_at)
+    const uint32_t* raw_slot_host = nullptr;   // source of its updates
     int64_t pack32_base[RT_MAX_LIGHTS] = {0};
     bool simple_shading = false;   // see SampleSums in rt_lighting_mixed.hip: coefficients in [0, 1], grey lights
     int64_t pack_base[RT_MAX_LIGHTS] = {0};
@@ -216,6 +225,9 @@ struct RtContext {
     DevBuf<long long> mt_end;
     DevBuf<unsigned long long> mt_need;     // store map of the generator (k_store_map)
     DevBuf<unsigned long long> mt_stat;
+    std::vector<int32_t> node_hits_host;    // the hits per node as rt_get_node_counts last read them ...
+    bool node_hits_host_valid = false;      // ... and no level 0 has been traced since
+    int mt_polys_ell = -1, mt_polys_n = 0;  // what mt_polys holds: the polynomials x^(2^(ell + b)), b < n
     long long generator_words = 0, generator_words_stored = 0;   // of the last rt_generate_samples
     uint8_t* user_image8 = nullptr;
     int32_t* user_batches = nullptr;
@@ -269,7 +281,7 @@ struct RtContext {
         D.spot_mask = spot_mask;
         D.X = explicit_xy ? X.p : nullptr; D.Y = explicit_xy ? Y.p : nullptr;
         D.row0 = row0; D.npix = (int32_t)npix;
-        D.packed = packed.p; D.pack_plane = pack_plane; D.packed32 = have_packed32 ? packed32.p : nullptr; D.pack_E = pack_E; D.sample_off = sample_off.p; D.sample_global = have_global_layout ? sample_global.p : nullptr;
+        D.packed = packed.p; D.pack_plane = pack_plane; D.packed32 = have_packed32 ? packed32.p : nullptr; D.raw_values_at = raw_slot.p; D.pack_E = pack_E; D.sample_off = sample_off.p; D.sample_global = have_global_layout ? sample_global.p : nullptr;
         for (int l = 0; l < RT_MAX_LIGHTS; ++l) { D.pack_base[l] = pack_base[l]; D.pack32_base[l] = pack32_base[l]; }
         D.image = user_image ? user_image : image.p;
         return D;
@@ -528,8 +540,12 @@ void rt_destroy(RtContext* ctx) {
     for (auto& b : ctx->list_j) b.release();
     ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->packed32.release(); ctx->staging.release();
     ctx->image.release(); ctx->image8.release(); ctx->mt_ring.release(); ctx->mt_raw.release(); ctx->mt_polys.release(); ctx->mt_end.release(); ctx->sample_off.release(); ctx->sample_global.release(); ctx->hit_mask.release(); ctx->hit_pref.release(); ctx->hit_word0.release(); ctx->emit_blocks.release(); ctx->work.release();
+    ctx->mt_need.release(); ctx->mt_stat.release(); ctx->raw_slot.release();
     if (ctx->bounce) (void)hipHostFree(ctx->bounce);
     for (auto e : ctx->bounce_done) if (e) (void)hipEventDestroy(e);
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+    if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -828,6 +844,7 @@ int rt_trace_level(RtContext* ctx, int32_t level) {
     if (level == 0) {
         // (re)start the frame on the pixels chosen by the last rt_begin_frame
         ctx->geometry_done = false;
+        ctx->node_hits_host_valid = false;
         ctx->frame_col32 = ctx->precision != RT_PRECISION_F64;   // k_trace, the lighting kernels and k_combine must agree
         ctx->begin(RT_K_INIT);
         hipLaunchKernelGGL(k_init, dim3(1), dim3(1024), 0, ctx->stream, ctx->dev());
@@ -890,6 +907,8 @@ int rt_get_node_counts(RtContext* ctx, int64_t* batch, int64_t* hits, int64_t* b
     HIP_TRY(hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (flag) return fail(RT_ERR_OVERFLOW, "ray arena of %lld rays is too small for this frame", (long long)ctx->arena_rays);
+    ctx->node_hits_host = h;   // rt_generate_samples needs them again
+    ctx->node_hits_host_valid = true;
     for (int k = 0; k < K; ++k) {
         if (batch) batch[k] = n[k];
         if (hits) hits[k] = h[k];
@@ -928,6 +947,9 @@ int rt_set_sample_layout(RtContext* ctx, const int64_t* offsets, int64_t total) 
         HIP_TRY(ctx->packed32.ensure((size_t)quads * 4));
     }
     ctx->disk_points_ready = false;
+    ctx->samples_in_raw = false;
+    HIP_TRY(ctx->raw_slot.ensure(1));
+    HIP_TRY(hipMemsetAsync(ctx->raw_slot.p, 0, sizeof(const uint32_t*), ctx->stream));
     HIP_TRY(hipMemcpy(ctx->sample_off.p, offsets, n * sizeof(int64_t), hipMemcpyHostToDevice));
     ctx->sample_off_host.assign(offsets, offsets + n);
     ctx->pack_E = entries;
@@ -957,12 +979,33 @@ int rt_set_sample_layout_global(RtContext* ctx, const int64_t* offsets, const in
     return RT_OK;
 }
 
+// Generated samples that were only packed as disk points (rt_generate_samples): their uniforms into
+// `packed` after all, from the raw words, for whoever reads that array or is about to change or release
+// either.  Allocates nothing.  Not under stream capture (the flag would change without the kernel running).
+static int materialize_packed(RtContext* ctx) {
+    if (!ctx->samples_in_raw) return RT_OK;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+        return fail(RT_ERR_STATE, "the disk-light samples have to be unpacked for this call, which cannot be captured into a graph");
+    if (ctx->pack_E > 0) {
+        const long long total = ctx->have_global_layout ? ctx->global_total : ctx->sample_total;
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB));
+        hipLaunchKernelGGL((k_pack<GeneratedStream>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(),
+                           GeneratedStream{ctx->mt_raw.p + ctx->raw_value0}, (int64_t)0, (int64_t)total, 0);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemsetAsync(ctx->raw_slot.p, 0, sizeof(const uint32_t*), ctx->stream));
+    ctx->samples_in_raw = false;
+    return RT_OK;
+}
+
 int rt_upload_samples(RtContext* ctx, int64_t dst_offset, const double* u, int64_t n) {
     if (int rc = use_device(ctx)) return rc;
     if (!ctx->layout_set) return fail(RT_ERR_STATE, "rt_set_sample_layout has not been called");
     if (n < 0 || dst_offset < 0 || dst_offset + n > ctx->sample_total) return fail(RT_ERR_INVALID, "sample range out of bounds");
     if (n == 0) return RT_OK;
     if (!u) return fail(RT_ERR_INVALID, "u is null");
+    if (int rc = materialize_packed(ctx)) return rc;
     // stage the piece of the stream, then scatter it into the packed layout
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx->staging.ensure((size_t)n));
@@ -988,6 +1031,7 @@ int rt_upload_samples_noalloc(RtContext* ctx, int64_t dst_offset, const double* 
                     (long long)RT_NOALLOC_MAX_SAMPLES, (long long)n);
     if (n == 0) return RT_OK;
     if (!u) return fail(RT_ERR_INVALID, "u is null");
+    if (int rc = materialize_packed(ctx)) return rc;
     // The staging array is shared by every call on this GPU and still holds the previous piece:
     // k_pack reads chunk[0 .. n) only, so nothing has to be cleared, but this context's previous
     // scatter must have finished reading before the array is overwritten.
@@ -1024,6 +1068,8 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     const long long total = ctx->have_global_layout ? ctx->global_total : ctx->sample_total;
     ctx->samples_delivered = 0;
     ctx->disk_points_ready = false;
+    ctx->samples_in_raw = false;
+    HIP_TRY(hipMemsetAsync(ctx->raw_slot.p, 0, sizeof(const uint32_t*), ctx->stream));
     if (total == 0) {
         ctx->samples_delivered = ctx->sample_total;
         memcpy(key_out, key, MT_N * sizeof(uint32_t));
@@ -1044,15 +1090,78 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     // words held in memory at a time (whole streams): all of them if a good part of the free device
     // memory holds them (then every stream is generated in one launch, four workgroups to a
     // compute unit); RT_MT_RAW_WORDS overrides for tests
-    size_t free_bytes = 0, total_bytes = 0;
-    HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
-    long long budget = std::max<long long>(1ll << 28, (long long)(free_bytes / 2 / sizeof(uint32_t)));
-    budget = std::max(budget, (long long)ctx->mt_raw.n);   // what an earlier call kept is there already
+    long long budget = (long long)ctx->mt_raw.n;            // what an earlier call kept is there already
+    if (budget < (long long)T * L + 2) {
+        size_t free_bytes = 0, total_bytes = 0;
+        HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
+        budget = std::max(budget, std::max<long long>(1ll << 28, (long long)(free_bytes / 2 / sizeof(uint32_t))));
+    }
     if (const char* e = getenv("RT_MT_RAW_WORDS")) budget = std::max(1ll, atoll(e));
     const int per_pass = (int)std::max<long long>(1, std::min<long long>(T, budget >> ell));
 
     HIP_TRY(ctx->mt_ring.ensure((size_t)T * MT_RING));
     HIP_TRY(ctx->mt_end.ensure((size_t)T));
+    std::vector<uint32_t> ring(MT_RING, 0u), first_ring(MT_RING, 0u);
+    memcpy(first_ring.data(), key, MT_N * sizeof(uint32_t));
+    const long long first_end = MT_N;
+    HIP_TRY(hipMemcpyAsync(ctx->mt_ring.p, first_ring.data(), MT_RING * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->mt_end.p, &first_end, sizeof first_end, hipMemcpyHostToDevice, ctx->stream));
+
+    bool jumping = false;
+    if (T > 1) {
+        // start windows of streams 1 .. T-1 by jump-ahead from the key block
+        int n_polys = 1;                                   // bits of T - 1, the largest t
+        while (((T - 1) >> n_polys) > 0) ++n_polys;
+        // every polynomial as the list of its set coefficients, round by round (JumpPoly in rt_samples.hip);
+        // what the last call uploaded is still there if it cut its stream the same way
+        const size_t head_words = (n_polys * sizeof(JumpPoly) / 4 + 3) / 4 * 4;
+        if (ctx->mt_polys_ell != ell || ctx->mt_polys_n != n_polys || !ctx->mt_polys.p) {
+            std::vector<uint32_t> words(MT_N);
+            std::vector<JumpPoly> heads(n_polys);
+            std::vector<uint32_t> lists;
+            for (int b = 0; b < n_polys; ++b) {
+                if (!mtjump::pow2_words(ell + b, words.data()))
+                    return fail(RT_ERR_INVALID, "MT19937 jump tables unavailable (stream too long?)");
+                std::vector<uint16_t> index;
+                for (int r = 0; r < MTJ_ROUNDS; ++r) {
+                    heads[b].first[r] = (int32_t)(lists.size() + index.size() / 2);
+                    for (int i = r * MTJ_CHUNK; i < std::min((r + 1) * MTJ_CHUNK, 19937); ++i)
+                        if ((words[i >> 5] >> (i & 31)) & 1u) index.push_back((uint16_t)i);
+                    while (index.size() % 16) index.push_back((uint16_t)MTJ_NONE);
+                }
+                for (size_t i = 0; i < index.size(); i += 2) lists.push_back((uint32_t)index[i] | ((uint32_t)index[i + 1] << 16));
+                heads[b].first[MTJ_ROUNDS] = (int32_t)lists.size();
+            }
+            // (one buffer: the heads, then the lists, 16-byte aligned)
+            std::vector<uint32_t> polys(head_words + lists.size() + 8, 0u);
+            memcpy(polys.data(), heads.data(), n_polys * sizeof(JumpPoly));
+            memcpy(polys.data() + head_words, lists.data(), lists.size() * 4);
+            ctx->mt_polys_ell = -1;
+            HIP_TRY(ctx->mt_polys.ensure(polys.size()));
+            HIP_TRY(hipMemcpy(ctx->mt_polys.p, polys.data(), polys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            ctx->mt_polys_ell = ell;
+            ctx->mt_polys_n = n_polys;
+        }
+        const uint32_t* device_lists = ctx->mt_polys.p + head_words;
+        // level b: the windows of streams 2^b .. min(2^(b+1), T) - 1 from those of streams 0 .. (one polynomial each),
+        // summed into zeroed rings; on a stream of their own, beside the hit mask and the store map
+        if (!ctx->side_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(ctx->side_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+        HIP_TRY(hipMemsetAsync(ctx->mt_ring.p + MT_RING, 0, (size_t)(T - 1) * MT_RING * sizeof(uint32_t), ctx->side_stream));
+        for (int b = 0; b < n_polys; ++b) {
+            const int count = std::min(1 << b, T - (1 << b));
+            if (count > 0)
+                hipLaunchKernelGGL(k_mt_jump, dim3(count * MTJ_ROUNDS), dim3(640), 0, ctx->side_stream, ctx->mt_ring.p, ctx->mt_end.p,
+                                   reinterpret_cast<const JumpPoly*>(ctx->mt_polys.p), device_lists, b, ell);
+        }
+        HIP_TRY(hipEventRecord(ctx->side_join, ctx->side_stream));
+        jumping = true;
+    }
     // RT_MT_FUSED=1, for scenes whose sampled lights are all plain disk lights: the generator stores every
     // value straight at its place in the packed layout (k_mt_emit) and no raw words reach device memory -
     // 4K example_4: 17 GB written instead of 50 + 19 + 17 GB moved and no 50 GB work buffer, but 33 ms
@@ -1063,17 +1172,23 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     // Default path: raw words nobody will read are not stored (k_store_map; RT_MT_STORE_ALL=1 stores all).
     bool mapped = !fused && ctx->pack_E > 0 && !getenv("RT_MT_STORE_ALL");
     int n_emit_blocks = 0;
+    // (sources of uploads that are queued on the stream: alive until the call's last synchronisation)
+    std::vector<uint32_t> word0;
+    std::vector<EmitBlock> blocks;
     if (fused || mapped) {
         const int K = ctx->tree.n_nodes(), Lv = ctx->tree.n_levels();
-        std::vector<int32_t> hits(K), shade_base(Lv + 1);
-        std::vector<uint32_t> pre((size_t)K * NCNT);
-        HIP_TRY(hipMemcpyAsync(hits.data(), ctx->node_hits.p, (size_t)K * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(shade_base.data(), ctx->lvl_shade_base.p, (size_t)(Lv + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(pre.data(), ctx->node_pre.p, pre.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        std::vector<uint32_t> word0(K + 1, 0u);
+        std::vector<int32_t> hits(K), shade_base(Lv + 1, 0);
+        std::vector<uint32_t> pre((size_t)K * NCNT, 0u);
+        if (mapped && ctx->node_hits_host_valid && (int)ctx->node_hits_host.size() == K) {
+            hits = ctx->node_hits_host;          // the map only needs the hits per node, and the host has read them
+        } else {
+            HIP_TRY(hipMemcpyAsync(hits.data(), ctx->node_hits.p, (size_t)K * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(shade_base.data(), ctx->lvl_shade_base.p, (size_t)(Lv + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(pre.data(), ctx->node_pre.p, pre.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        word0.assign(K + 1, 0u);
         for (int k = 0; k < K; ++k) word0[k + 1] = word0[k] + (uint32_t)((hits[k] + 63) / 64);
-        std::vector<EmitBlock> blocks;
         const bool whole = ctx->have_global_layout;
         const size_t KL = (size_t)K * RT_MAX_LIGHTS;
         for (int k = 0; k < K; ++k)
@@ -1125,7 +1240,6 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
             HIP_TRY(hipMemcpyAsync(ctx->hit_word0.p, word0.data(), word0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(hipMemcpyAsync(ctx->emit_blocks.p, blocks.data(), blocks.size() * sizeof(EmitBlock), hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(hipMemsetAsync(ctx->hit_mask.p, 0, ((size_t)word0[K] + 2) * 8, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));   // the host vectors go out of scope
             const Dev Dm = ctx->dev();
             for (int level = 0; level < Lv; ++level)
                 hipLaunchKernelGGL(k_hitmask, dim3(ctx->nb), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, Dm, level, ctx->hit_word0.p, ctx->hit_mask.p);
@@ -1135,58 +1249,13 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     }
     ctx->mt_raw.transient = true;
     if (!fused) HIP_TRY(ctx->mt_raw.ensure((size_t)per_pass * L + 2));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    std::vector<uint32_t> ring(MT_RING, 0u);
-    memcpy(ring.data(), key, MT_N * sizeof(uint32_t));
-    const long long first_end = MT_N;
-    HIP_TRY(hipMemcpy(ctx->mt_ring.p, ring.data(), MT_RING * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->mt_end.p, &first_end, sizeof first_end, hipMemcpyHostToDevice));
-
-    if (T > 1) {
-        // start windows of streams 1 .. T-1 by jump-ahead from the key block
-        int n_polys = 1;                                   // bits of T - 1, the largest t
-        while (((T - 1) >> n_polys) > 0) ++n_polys;
-        // every polynomial as the list of its set coefficients, round by round (JumpPoly in rt_samples.hip)
-        std::vector<uint32_t> words(MT_N);
-        std::vector<JumpPoly> heads(n_polys);
-        std::vector<uint32_t> lists;
-        for (int b = 0; b < n_polys; ++b) {
-            if (!mtjump::pow2_words(ell + b, words.data()))
-                return fail(RT_ERR_INVALID, "MT19937 jump tables unavailable (stream too long?)");
-            std::vector<uint16_t> index;
-            for (int r = 0; r < MTJ_ROUNDS; ++r) {
-                heads[b].first[r] = (int32_t)(lists.size() + index.size() / 2);
-                for (int i = r * MTJ_CHUNK; i < std::min((r + 1) * MTJ_CHUNK, 19937); ++i)
-                    if ((words[i >> 5] >> (i & 31)) & 1u) index.push_back((uint16_t)i);
-                while (index.size() % 16) index.push_back((uint16_t)MTJ_NONE);
-            }
-            for (size_t i = 0; i < index.size(); i += 2) lists.push_back((uint32_t)index[i] | ((uint32_t)index[i + 1] << 16));
-            heads[b].first[MTJ_ROUNDS] = (int32_t)lists.size();
-        }
-        // (one buffer: the heads, then the lists, 16-byte aligned)
-        const size_t head_words = (n_polys * sizeof(JumpPoly) / 4 + 3) / 4 * 4;
-        std::vector<uint32_t> polys(head_words + lists.size() + 8, 0u);
-        memcpy(polys.data(), heads.data(), n_polys * sizeof(JumpPoly));
-        memcpy(polys.data() + head_words, lists.data(), lists.size() * 4);
-        HIP_TRY(ctx->mt_polys.ensure(polys.size()));
-        HIP_TRY(hipMemcpy(ctx->mt_polys.p, polys.data(), polys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        const uint32_t* device_lists = ctx->mt_polys.p + head_words;
-        // level b: the windows of streams 2^b .. min(2^(b+1), T) - 1 from those of streams 0 .. (one polynomial each),
-        // summed into zeroed rings
-        HIP_TRY(hipMemsetAsync(ctx->mt_ring.p + MT_RING, 0, (size_t)(T - 1) * MT_RING * sizeof(uint32_t), ctx->stream));
-        for (int b = 0; b < n_polys; ++b) {
-            const int count = std::min(1 << b, T - (1 << b));
-            if (count > 0)
-                hipLaunchKernelGGL(k_mt_jump, dim3(count * MTJ_ROUNDS), dim3(640), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p,
-                                   reinterpret_cast<const JumpPoly*>(ctx->mt_polys.p), device_lists, b, ell);
-        }
-    }
     // The state NumPy would be left in: the key block that holds the last word consumed and
     // the position after it (a position of 624 means "regenerate at the next draw").
     const long long block = (next - 1) / MT_N;
     const int last_stream = T - 1;
     const Dev D = ctx->dev();
     const int64_t pack_blocks = std::max<int64_t>(1, std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB));
+    if (jumping) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
     if (fused)
         hipLaunchKernelGGL(k_mt_emit, dim3(T), dim3(256), 0, ctx->stream, D, ctx->mt_ring.p, ctx->mt_end.p, ell, (long long)pos, total, next,
                            last_stream, (block + 1) * MT_N, ctx->emit_blocks.p, getenv("RT_EMIT_GENERATE_ONLY") ? -1 : n_emit_blocks, ctx->hit_mask.p, ctx->hit_pref.p);
@@ -1199,10 +1268,10 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         HIP_TRY(ctx->mt_need.ensure((size_t)T * need_words));
         HIP_TRY(ctx->mt_stat.ensure(1));
         HIP_TRY(hipMemsetAsync(ctx->mt_stat.p, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_store_map, dim3((unsigned)((n_bytes + 255) / 256)), dim3(256), 0, ctx->stream, ctx->emit_blocks.p, n_emit_blocks, ctx->hit_mask.p,
+        hipLaunchKernelGGL(k_store_map, dim3((unsigned)std::min<long long>((n_bytes + 255) / 256, 8192)), dim3(256), 0, ctx->stream, ctx->emit_blocks.p, n_emit_blocks, ctx->hit_mask.p,
                            (long long)pos, total, ell, steps_per_stream, need_words * 8, n_bytes, reinterpret_cast<uint8_t*>(ctx->mt_need.p), ctx->mt_stat.p);
     }
-    bool points_made = false;
+    bool points_made = false, raw_only = false;
     for (int t0 = 0; t0 < T && !fused; t0 += per_pass) {
         const int n_streams = std::min(per_pass, T - t0);
         const long long w_lo = (long long)t0 << ell;                                   // origin of the pass's buffer
@@ -1216,10 +1285,21 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         const long long p_hi = (w_hi - 2 - pos) / 2;                                   // inclusive
         // one pass over the whole stream: the float32 pass's disk points are made along the way
         const bool with_points = per_pass >= T && p_lo == 0 && p_hi + 1 == total && ctx->have_packed32 && ctx->precision != RT_PRECISION_F64;
+        // ... and if the raw words stay with the context, the points are all that is written: the few hits
+        // whose float32 lighting cannot be certified read their uniforms from the raw words (RT_PACK_UNIFORMS=1: always both)
+        const bool points_only = with_points && ctx->precision == RT_PRECISION_MIXED && ctx->mt_raw.n * sizeof(uint32_t) <= mt_raw_keep_bytes() &&
+                                 !getenv("RT_PACK_UNIFORMS");
         if (ctx->pack_E > 0 && p_hi >= p_lo && w_hi - 2 - pos >= 0) {
             hipLaunchKernelGGL((k_pack<GeneratedStream>), dim3((unsigned)pack_blocks), dim3(BLOCK), 0, ctx->stream, D,
-                               GeneratedStream{ctx->mt_raw.p + (pos + 2 * p_lo - w_lo)}, (int64_t)p_lo, (int64_t)(p_hi - p_lo + 1), with_points ? 1 : 0);
+                               GeneratedStream{ctx->mt_raw.p + (pos + 2 * p_lo - w_lo)}, (int64_t)p_lo, (int64_t)(p_hi - p_lo + 1),
+                               points_only ? 2 : with_points ? 1 : 0);
             if (with_points) points_made = true;
+            if (points_only) {
+                raw_only = true;
+                ctx->raw_value0 = pos - w_lo;
+                ctx->raw_slot_host = ctx->mt_raw.p + ctx->raw_value0;
+                HIP_TRY(hipMemcpyAsync(ctx->raw_slot.p, &ctx->raw_slot_host, sizeof(const uint32_t*), hipMemcpyHostToDevice, ctx->stream));
+            }
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1230,6 +1310,8 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     if (last_stream > 0)
         HIP_TRY(hipMemcpyAsync(prev_ring.data(), ctx->mt_ring.p + (size_t)(last_stream - 1) * MT_RING, MT_RING * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long kept = 0;
+    if (mapped) HIP_TRY(hipMemcpyAsync(&kept, ctx->mt_stat.p, sizeof kept, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const long long last_first = (long long)last_stream << ell;
     for (int i = 0; i < MT_N; ++i) {
@@ -1239,13 +1321,10 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     *pos_out = (int32_t)(next - block * MT_N);
     ctx->samples_delivered = ctx->sample_total;   // the whole stream of this context has been made
     ctx->disk_points_ready = points_made;
+    ctx->samples_in_raw = raw_only;
     ctx->generator_words = next;
     ctx->generator_words_stored = fused ? 0 : next;
-    if (mapped) {
-        unsigned long long kept = 0;
-        HIP_TRY(hipMemcpy(&kept, ctx->mt_stat.p, sizeof kept, hipMemcpyDeviceToHost));
-        ctx->generator_words_stored = (long long)kept + (long long)T * MT_N;   // and every stream's window
-    }
+    if (mapped) ctx->generator_words_stored = (long long)kept + (long long)T * MT_N;   // and every stream's window
     // The raw words are only needed while they are being packed, but getting device memory back that
     // some process has used before takes the driver tens of milliseconds per GB (measured: 1.3 s for
     // the 50 GB of a 4K example_4 frame, every call), so a buffer of moderate size stays with the context.
@@ -1255,8 +1334,10 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
 
 int rt_trim(RtContext* ctx) {
     if (int rc = use_device(ctx)) return rc;
+    if (int rc = materialize_packed(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->mt_raw.release(); ctx->mt_ring.release(); ctx->mt_end.release(); ctx->mt_polys.release(); ctx->mt_need.release();
+    ctx->mt_raw.release(); ctx->mt_ring.release(); ctx->mt_end.release(); ctx->mt_polys.release(); ctx->mt_need.release(); ctx->mt_stat.release();
+    ctx->mt_polys_ell = -1;
     ctx->staging.release(); ctx->hit_mask.release(); ctx->hit_pref.release(); ctx->hit_word0.release(); ctx->emit_blocks.release();
     return RT_OK;
 }
@@ -1275,11 +1356,13 @@ int rt_shade(RtContext* ctx) {
     if (ctx->sampled_lights && ctx->samples_delivered < ctx->sample_total)
         return fail(RT_ERR_STATE, "only %lld of the %lld disk-light sample values have been uploaded or generated",
                     (long long)ctx->samples_delivered, (long long)ctx->sample_total);
-    const Dev D = ctx->dev();
     const bool lds = ctx->S <= SHADE_LDS_SPHERES;
     // (the float32 sample pass stores float32 colours: only for frames whose geometry ran in mixed precision)
     const bool mixed = ctx->precision != RT_PRECISION_F64 && ctx->frame_col32 && ctx->sampled_lights && ctx->S <= MIXED_MAX_SPHERES && ctx->have_packed32;
     const bool check = ctx->precision == RT_PRECISION_MIXED_CHECKED;
+    if (mixed && check)
+        if (int rc = materialize_packed(ctx)) return rc;   // the checking pass reads every sample's uniforms
+    const Dev D = ctx->dev();
     if (mixed && !ctx->disk_points_ready) {
         // once per sample stream (not per frame): the float32 pass reads disk points, see k_disk_points.
         // Not while the stream is being captured: the kernel would be recorded, not run, and a later

@@ -170,6 +170,11 @@ struct Dev {
     // floats, tile by tile of 64 shading-list entries; light l, tile t, samples 2p and 2p + 1 of entry
     // 64 t + i are the float4 (x0, x1, y0, y1) at index pack32_base[l] + (t * ceil(N / 2) + p) * 64 + i
     float* packed32;
+    // *raw_values_at not null: `packed` has not been filled; value i of the stream is made of the generator's
+    // raw words raw_values[2 i] and raw_values[2 i + 1] (GeneratedStream), positions as sample_column<true>
+    // gives them.  Read from device memory when the kernel runs, not passed by value: a launch recorded in
+    // a graph must follow the samples when they are moved into `packed` later (materialize_packed).
+    const uint32_t* const* raw_values_at;
     int64_t pack32_base[RT_MAX_LIGHTS];
     int64_t pack_base[RT_MAX_LIGHTS];
     int64_t pack_E;             // entries of the shading list when the samples were packed

@@ -320,9 +320,16 @@ __device__ V3 surface_color(const Dev& D, const SceneConst& sc, const ShadowSphe
         n_samples += N;
         const double* pk = D.packed + D.pack_base[l] + entry;   // + pack_E per sample
         const int64_t stride = D.pack_E;
+        // (samples that were generated on the device and only packed as disk points: from the raw words)
+        const uint32_t* raw_values = D.raw_values_at ? *D.raw_values_at : nullptr;
+        const GeneratedStream raw{raw_values};
+        SampleColumn col{0, 0, false};
+        if (raw_values) col = sample_column<true>(D, entry, D.list_node[entry], info, l, Lt);
         V3 sumId = {0, 0, 0}, sumIs = {0, 0, 0}, sumKd = {0, 0, 0}, sumKs = {0, 0, 0};
         for (int s = 0; s < N; ++s) {
-            const SampleTerms o = disk_sample_f64<LDS, GRID>(D, s_sh, cand, Lt, pk[s * stride], pk[D.pack_plane + s * stride],
+            const double u_angle = raw_values ? raw(col.first + s * col.h) : pk[s * stride];
+            const double u_radius = raw_values ? raw(col.first + ((int64_t)N + s) * col.h) : pk[D.pack_plane + s * stride];
+            const SampleTerms o = disk_sample_f64<LDS, GRID>(D, s_sh, cand, Lt, u_angle, u_radius,
                                                        Pb, d, n, kdiff, kspec, shin);
             sumId = sumId + o.Id; sumIs = sumIs + o.Is; sumKd = sumKd + o.kd; sumKs = sumKs + o.ks;
         }

@@ -49,9 +49,44 @@ __device__ __forceinline__ void disk_point(double u_angle, double u_radius, floa
     y = (float)(rad * sn);
 }
 
+// Where the samples of shading-list entry e under the sampled light l sit in the stream: the angle
+// uniform of sample s at first + s * h, its radius uniform n_points * h further on (h: the node's hits, or
+// its in-beam hits for a spotlight; the hit's rank among them is its column).  WHOLE_IMAGE: positions in
+// the whole image's stream where the context has such a layout.  any == false: the entry draws none.
+struct SampleColumn {
+    int64_t first, h;
+    bool any;
+};
+template <bool WHOLE_IMAGE>
+__device__ __forceinline__ SampleColumn sample_column(const Dev& D, int64_t e, int node, uint32_t info, int l, const RtLight& Lt) {
+    SampleColumn c;
+    int64_t jj;
+    c.any = true;
+    if (Lt.kind == RT_LIGHT_SPOT) {
+        c.any = (info >> (I_BEAM_SHIFT + l)) & 1u;
+        c.h = D.node_beam[node * RT_MAX_LIGHTS + l];
+        jj = D.list_j[1 + l][e];
+    } else {
+        c.h = D.node_hits[node];
+        jj = D.list_j[0][e];
+    }
+    int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
+    c.any = c.any && off >= 0;
+    if (WHOLE_IMAGE && D.sample_global) {
+        // this context holds columns [first column, + h) of a block that is wider in the whole image's stream
+        const size_t KL = (size_t)D.K * RT_MAX_LIGHTS, at = (size_t)node * RT_MAX_LIGHTS + l;
+        off = D.sample_global[at];
+        c.h = D.sample_global[KL + at];
+        jj += D.sample_global[2 * KL + at];
+    }
+    c.first = off + jj;
+    return c;
+}
+
 // with_points (the piece [a, a + n) is the whole stream and the scene's samples go through the float32
 // pass): the entry's disk points are made here as well, from the values just read, and k_disk_points
-// need not read the packed uniforms again.
+// need not read the packed uniforms again.  with_points == 2: only the points - the float64 readers
+// (the re-evaluation of uncertified hits) take their uniforms from the raw words, Dev::raw_values_at.
 template <typename Stream>
 __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, int64_t n, int with_points) {
     const SceneConst& sc = *D.sc;
@@ -73,73 +108,37 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, 
         for (int l = 0; l < D.n_lights; ++l) {
             const RtLight& Lt = sc.lights[l];
             if (Lt.kind == RT_LIGHT_POINT) continue;
+            const SampleColumn c = sample_column<Stream::WHOLE_IMAGE>(D, e, node, info, l, Lt);
+            const int N = Lt.n_points;
+            double* dst = D.packed + D.pack_base[l] + e;
             if (with_points) {
                 // both uniforms of a sample together: packed as below, and the point they select
-                const int N = Lt.n_points, NP = (N + 1) >> 1;
+                const int NP = (N + 1) >> 1;
                 float4* points = reinterpret_cast<float4*>(D.packed32) + D.pack32_base[l] + (e / TILE) * NP * TILE + (e % TILE);
-                int64_t h, jj;
-                bool lit = true;
-                if (Lt.kind == RT_LIGHT_SPOT) {
-                    lit = (info >> (I_BEAM_SHIFT + l)) & 1u;
-                    h = D.node_beam[node * RT_MAX_LIGHTS + l];
-                    jj = D.list_j[1 + l][e];
-                } else {
-                    h = D.node_hits[node];
-                    jj = D.list_j[0][e];
-                }
-                int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
-                if (Stream::WHOLE_IMAGE && D.sample_global) {
-                    const size_t KL = (size_t)D.K * RT_MAX_LIGHTS, at = (size_t)node * RT_MAX_LIGHTS + l;
-                    off = D.sample_global[at];
-                    h = D.sample_global[KL + at];
-                    jj += D.sample_global[2 * KL + at];
-                }
-                lit = lit && off >= 0;
-                double* dst = D.packed + D.pack_base[l] + e;
                 for (int p = 0; p < NP; ++p) {
                     float x[2] = {0, 0}, y[2] = {0, 0};
                     for (int k = 0; k < 2; ++k) {
                         const int s = 2 * p + k;
-                        if (s >= N || !lit) break;
-                        const double u_angle = chunk(off + s * h + jj - a), u_radius = chunk(off + (int64_t)N * h + s * h + jj - a);
-                        dst[s * E] = u_angle;
-                        dst[D.pack_plane + s * E] = u_radius;
+                        if (s >= N || !c.any) break;
+                        const double u_angle = chunk(c.first + s * c.h - a), u_radius = chunk(c.first + ((int64_t)N + s) * c.h - a);
+                        if (with_points != 2) {
+                            dst[s * E] = u_angle;
+                            dst[D.pack_plane + s * E] = u_radius;
+                        }
                         disk_point(u_angle, u_radius, x[k], y[k]);
                     }
                     points[(int64_t)p * TILE] = make_float4(x[0], x[1], y[0], y[1]);
                 }
                 continue;
             }
-            int64_t h, jj;
-            if (Lt.kind == RT_LIGHT_SPOT) {
-                if (!((info >> (I_BEAM_SHIFT + l)) & 1u)) continue;
-                h = D.node_beam[node * RT_MAX_LIGHTS + l];
-                jj = D.list_j[1 + l][e];
-            } else {
-                h = D.node_hits[node];
-                jj = D.list_j[0][e];
-            }
-            const int N = Lt.n_points;
-            int64_t off = D.sample_off[(size_t)node * RT_MAX_LIGHTS + l];
-            if (off < 0) continue;
-            if (Stream::WHOLE_IMAGE && D.sample_global) {
-                // this context holds columns [first column, + h) of a block that is wider in the
-                // whole image's stream
-                const size_t KL = (size_t)D.K * RT_MAX_LIGHTS, at = (size_t)node * RT_MAX_LIGHTS + l;
-                off = D.sample_global[at];
-                h = D.sample_global[KL + at];
-                jj += D.sample_global[2 * KL + at];
-            }
-            if (off + 2 * N * h <= a || off >= b) continue;
-            double* dst = D.packed + D.pack_base[l] + e;
+            if (!c.any || c.first >= b || c.first + (2 * (int64_t)N - 1) * c.h < a) continue;   // none of its values in the piece
             for (int part = 0; part < 2; ++part) {
-                const int64_t first = off + (int64_t)part * N * h + jj;     // stream position of row 0
-                int64_t s0 = first >= a ? 0 : (a - first + h - 1) / h;
+                const int64_t first = c.first + (int64_t)part * N * c.h;     // stream position of row 0
+                int64_t s0 = first >= a ? 0 : (a - first + c.h - 1) / c.h;
                 for (int64_t s = s0; s < N; ++s) {
-                    const int64_t pos = first + s * h;
+                    const int64_t pos = first + s * c.h;
                     if (pos >= b) break;
-                    const double u = chunk(pos - a);
-                    dst[part * D.pack_plane + s * E] = u;
+                    dst[part * D.pack_plane + s * E] = chunk(pos - a);
                 }
             }
         }
@@ -445,16 +444,14 @@ __device__ unsigned store_map_bits(const EmitBlock* __restrict__ blocks, int n_b
 __global__ __launch_bounds__(256) void k_store_map(const EmitBlock* __restrict__ blocks, int n_blocks, const unsigned long long* __restrict__ mask,
                                                    long long pos, long long n_values, int ell, int steps_per_stream, int bytes_per_stream,
                                                    long long n_bytes, uint8_t* __restrict__ need, unsigned long long* __restrict__ words_kept) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    unsigned bits = 0;
-    if (i < n_bytes) {
-        bits = store_map_bits(blocks, n_blocks, mask, pos, n_values, ell, steps_per_stream, bytes_per_stream, i);
+    unsigned long long words = 0;   // statistics: words the generator will store (64 per wave, 35 for the fourth)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_bytes; i += (long long)gridDim.x * 256) {
+        const unsigned bits = store_map_bits(blocks, n_blocks, mask, pos, n_values, ell, steps_per_stream, bytes_per_stream, i);
         need[i] = (uint8_t)bits;
+        words += 64u * (unsigned)__popc(bits & 7u) + (unsigned)(MT_STEP - 192) * (bits >> 3);
     }
-    // statistics: words the generator will store (64 per wave, 35 for the fourth)
-    unsigned words = 64u * (unsigned)__popc(bits & 7u) + (unsigned)(MT_STEP - 192) * (bits >> 3);
     for (int off = 32; off > 0; off >>= 1) words += __shfl_down(words, off);
-    if ((threadIdx.x & 63) == 0 && words) atomicAdd(words_kept, (unsigned long long)words);
+    if ((threadIdx.x & 63) == 0 && words) atomicAdd(words_kept, words);
 }
 
 // grid: one workgroup per stream t = blockIdx.x (see k_mt_generate for rings, gen_ends, ell, last_stream,

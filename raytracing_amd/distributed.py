@@ -356,14 +356,19 @@ class ShardedRenderer:
         while True:
             self.begin(output_ptr)
             self.trace()
-            overflow = int(self.ctx.counters()["overflow"])
+            from ._native import RtOverflow
+            try:
+                counts = self.ctx.node_counts()     # (one read-back: the counts and the overflow flag)
+                overflow = 0
+            except RtOverflow:
+                counts, overflow = None, 1
             if int(self.comm.all_reduce_sum(np.array([overflow], dtype=np.int64))[0]) == 0:
                 break
             self.arena_rays *= 2
-        self.collect_counts()
+        self.collect_counts(counts)
 
-    def collect_counts(self):
-        batch, hits, beam = self.ctx.node_counts()
+    def collect_counts(self, counts=None):
+        batch, hits, beam = self.ctx.node_counts() if counts is None else counts
         self.local_batch, self.local_hits, self.local_beam = batch, hits, beam
         packed = np.concatenate([batch[:, None], hits[:, None], beam], axis=1).astype(np.int64)
         every = self.comm.all_gather(packed)                      # (world, K, 2 + L)
@@ -381,7 +386,10 @@ class ShardedRenderer:
         rng = np.random if rng is None else rng
         lights, r = self.flat.lights, self.comm.rank
         g_off, g_cnt, g_total = sample_offsets(self.tree, lights, self.global_hits, self.global_beam)
-        l_off, l_cnt, l_total = sample_offsets(self.tree, lights, self.local_hits, self.local_beam)
+        if self.comm.sharded:
+            l_off, l_cnt, l_total = sample_offsets(self.tree, lights, self.local_hits, self.local_beam)
+        else:
+            l_off, l_cnt, l_total = g_off, g_cnt, g_total
         self.ctx.set_sample_layout(l_off, l_total)
         self.samples_total = l_total
         if not self.comm.sharded:

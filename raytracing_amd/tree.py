@@ -110,17 +110,19 @@ def sample_offsets(tree, lights, node_hits, node_beam):
     K, L = tree.n_nodes, len(lights)
     offsets = np.full((K, max(L, 1)), -1, dtype=np.int64)
     counts = np.zeros((K, max(L, 1)), dtype=np.int64)
-    cursor = 0
-    for node in tree.post_order():
-        if node_hits[node] == 0:
-            continue
-        for l, light in enumerate(lights):
-            if not light.draws_samples:
-                continue
-            h = int(node_beam[node, l]) if light.kind == 2 else int(node_hits[node])
-            if h == 0:
-                continue
-            offsets[node, l] = cursor
-            counts[node, l] = h
-            cursor += 2 * light.n_points * h
-    return offsets, counts, cursor
+    if L == 0:
+        return offsets, counts, 0
+    order = getattr(tree, "_post_order", None)
+    if order is None:
+        order = tree._post_order = tree.post_order()
+    hits = np.asarray(node_hits, dtype=np.int64).reshape(K)
+    for l, light in enumerate(lights):
+        if light.draws_samples:
+            h = np.asarray(node_beam, dtype=np.int64).reshape(K, -1)[:, l] if light.kind == 2 else hits
+            counts[:, l] = np.where(hits != 0, h, 0)
+    n_points = np.array([light.n_points if light.draws_samples else 0 for light in lights], dtype=np.int64)
+    sizes = (2 * n_points[None, :] * counts[:, :L])[order]            # in drawing order: node by node, light by light
+    ends = np.cumsum(sizes.ravel())
+    starts = (ends - sizes.ravel()).reshape(sizes.shape)
+    offsets[order, :L] = np.where(sizes > 0, starts, -1)
+    return offsets, counts, int(ends[-1]) if ends.size else 0

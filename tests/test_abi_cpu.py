@@ -72,6 +72,34 @@ def test_device_count_never_fails():
     assert _native.load_library().rt_device_count() >= 0
 
 
+def test_sample_offsets_equal_the_plain_loop():
+    """The offsets as a loop in the order the reference draws: nodes in post-order, lights in scene order."""
+    from types import SimpleNamespace as L
+    rs = np.random.RandomState(11)
+    for depths in ((3, 5), (2, 0), (0, 0), (1, 4)):
+        t = build_tree(*depths)
+        K = t.n_nodes
+        for lights in ([], [L(kind=0, draws_samples=False, n_points=1)],
+                       [L(kind=1, draws_samples=True, n_points=30)],
+                       [L(kind=2, draws_samples=True, n_points=7), L(kind=0, draws_samples=False, n_points=1), L(kind=1, draws_samples=True, n_points=3)]):
+            hits = rs.randint(0, 50, K) * (rs.rand(K) < 0.7)
+            beam = np.minimum(rs.randint(0, 50, (K, 8)), hits[:, None]) * (rs.rand(K, 8) < 0.8)
+            off, cnt, total = sample_offsets(t, lights, hits, beam)
+            want_off = np.full((K, max(len(lights), 1)), -1, dtype=np.int64)
+            want_cnt = np.zeros_like(want_off)
+            cursor = 0
+            for node in t.post_order():
+                if hits[node] == 0:
+                    continue
+                for l, light in enumerate(lights):
+                    h = int(beam[node, l]) if light.kind == 2 else int(hits[node])
+                    if not light.draws_samples or h == 0:
+                        continue
+                    want_off[node, l], want_cnt[node, l] = cursor, h
+                    cursor += 2 * light.n_points * h
+            assert total == cursor and np.array_equal(off, want_off) and np.array_equal(cnt, want_cnt)
+
+
 def test_sample_offsets_follow_post_order():
     t = build_tree(1, 1)   # root, t-child, i-child, r-child, and the r-child's t-child ...
     K = t.n_nodes

@@ -135,6 +135,59 @@ def test_trim_gives_the_sample_work_buffers_back():
         assert np.array_equal(r.render_pixels(), first)
 
 
+def test_samples_kept_as_raw_words_follow_every_later_call(monkeypatch):
+    """Generated samples are packed as disk points only; the float64 readers (re-evaluation of hits the
+    float32 pass cannot certify, the checking pass, float64 shading) take the uniforms from the raw words,
+    or from the packed array once something has moved them there (rt_trim, the checking mode).  Every
+    route gives the frame of RT_PACK_UNIFORMS=1 bit for bit - also a shading graph recorded before rt_trim."""
+    import torch
+    from raytracing_amd.raytrace import Renderer
+    scene = build_scene("example_4", 320, 180)
+    stream = torch.cuda.Stream()
+
+    def frames(packed):
+        if packed:
+            monkeypatch.setenv("RT_PACK_UNIFORMS", "1")
+        else:
+            monkeypatch.delenv("RT_PACK_UNIFORMS", raising=False)
+        out = {}
+        with torch.cuda.stream(stream):
+            with Renderer(scene, stream=stream.cuda_stream) as r:
+                r.begin_rows(0, 180)
+                np.random.seed(8)
+                r.trace()
+                r.draw_samples()
+                r.ctx.shade()
+                out["mixed"] = r.image().copy()
+                out["fallback"] = r.ctx.counters()["fallback_samples"]
+                g = torch.cuda.CUDAGraph()
+                g.capture_begin(capture_error_mode="relaxed")
+                try:
+                    r.ctx.shade()
+                finally:
+                    g.capture_end()
+                r.ctx.set_precision("f64")               # float64 lighting over the float32 colour arrays of this frame
+                r.ctx.shade()
+                out["f64"] = r.image().copy()
+                r.ctx.set_precision("mixed")
+                r.ctx.trim()                             # the raw words go away: the uniforms are unpacked first
+                g.replay()
+                stream.synchronize()
+                out["replayed after trim"] = r.image().copy()
+                r.ctx.set_precision("mixed_checked")
+                r.ctx.shade()
+                out["checked"] = r.image().copy()
+                out["mismatches"] = r.ctx.counters()["certify_mismatches"]
+        return out
+
+    lean, full = frames(False), frames(True)
+    assert lean["fallback"] > 0 and lean["fallback"] == full["fallback"]      # some hits do take the float64 route
+    assert lean["mismatches"] == 0 and full["mismatches"] == 0
+    for key in ("mixed", "f64", "replayed after trim", "checked"):
+        assert np.array_equal(lean[key], full[key]), key
+    assert np.array_equal(lean["mixed"], lean["replayed after trim"]) and np.array_equal(lean["mixed"], lean["checked"])
+
+
 def test_first_shade_after_new_samples_is_refused_under_stream_capture():
     """The first rt_shade after uploaded disk-light samples converts them for the float32 pass; recorded
     into a graph that conversion would not run when a later, uncaptured rt_shade expects it.  The call
