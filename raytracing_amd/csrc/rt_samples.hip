@@ -396,8 +396,12 @@ __device__ __forceinline__ bool any_mask_bits(const unsigned long long* __restri
     }
     return false;
 }
-// the byte of step i % bytes_per_stream of stream i / bytes_per_stream
-__device__ unsigned store_map_bits(const EmitBlock* __restrict__ blocks, int n_blocks, const unsigned long long* __restrict__ mask,
+// the byte of step i % bytes_per_stream of stream i / bytes_per_stream; block k's offset is offsets[k * STRIDE]
+// (a copy in LDS, or the blocks themselves)
+constexpr int MAP_LDS_BLOCKS = 2048;
+static_assert(sizeof(EmitBlock) % sizeof(int64_t) == 0 && offsetof(EmitBlock, off) == 0, "the blocks as an array of offsets with a stride");
+template <int STRIDE>
+__device__ unsigned store_map_bits(const EmitBlock* __restrict__ blocks, const int64_t* offsets, int n_blocks, const unsigned long long* __restrict__ mask,
                                    long long pos, long long n_values, int ell, int steps_per_stream, int bytes_per_stream, long long i) {
     const long long t = i / bytes_per_stream;
     const int step = (int)(i - t * bytes_per_stream);
@@ -412,7 +416,7 @@ __device__ unsigned store_map_bits(const EmitBlock* __restrict__ blocks, int n_b
     int lo = 0, hi = n_blocks - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (blocks[mid].off <= v_first) lo = mid; else hi = mid - 1;
+        if (offsets[(size_t)mid * STRIDE] <= v_first) lo = mid; else hi = mid - 1;
     }
     const EmitBlock B = blocks[lo];
     if (B.light == EMIT_ALWAYS || v_first < B.off || v_last >= B.end) return 0xF;
@@ -444,9 +448,19 @@ __device__ unsigned store_map_bits(const EmitBlock* __restrict__ blocks, int n_b
 __global__ __launch_bounds__(256) void k_store_map(const EmitBlock* __restrict__ blocks, int n_blocks, const unsigned long long* __restrict__ mask,
                                                    long long pos, long long n_values, int ell, int steps_per_stream, int bytes_per_stream,
                                                    long long n_bytes, uint8_t* __restrict__ need, unsigned long long* __restrict__ words_kept) {
+    // the blocks' offsets for the search: in LDS if they fit (every workgroup goes through many steps)
+    __shared__ int64_t s_off[MAP_LDS_BLOCKS];
+    const bool staged = n_blocks <= MAP_LDS_BLOCKS;
+    if (staged) {
+        for (int k = threadIdx.x; k < n_blocks; k += 256) s_off[k] = blocks[k].off;
+        __syncthreads();
+    }
     unsigned long long words = 0;   // statistics: words the generator will store (64 per wave, 35 for the fourth)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_bytes; i += (long long)gridDim.x * 256) {
-        const unsigned bits = store_map_bits(blocks, n_blocks, mask, pos, n_values, ell, steps_per_stream, bytes_per_stream, i);
+        unsigned bits;
+        if (staged) bits = store_map_bits<1>(blocks, s_off, n_blocks, mask, pos, n_values, ell, steps_per_stream, bytes_per_stream, i);
+        else bits = store_map_bits<sizeof(EmitBlock) / sizeof(int64_t)>(blocks, reinterpret_cast<const int64_t*>(blocks), n_blocks, mask, pos, n_values, ell,
+                                                                       steps_per_stream, bytes_per_stream, i);
         need[i] = (uint8_t)bits;
         words += 64u * (unsigned)__popc(bits & 7u) + (unsigned)(MT_STEP - 192) * (bits >> 3);
     }
