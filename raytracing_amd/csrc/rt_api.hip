@@ -1126,8 +1126,8 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
                 for (int r = 0; r < MTJ_ROUNDS; ++r) {
                     heads[b].first[r] = (int32_t)(lists.size() + index.size() / 2);
                     for (int i = r * MTJ_CHUNK; i < std::min((r + 1) * MTJ_CHUNK, 19937); ++i)
-                        if ((words[i >> 5] >> (i & 31)) & 1u) index.push_back((uint16_t)i);
-                    while (index.size() % 16) index.push_back((uint16_t)MTJ_NONE);
+                        if ((words[i >> 5] >> (i & 31)) & 1u) index.push_back((uint16_t)mtj_offset(i, r));
+                    while (index.size() % 16) index.push_back((uint16_t)MTJ_PAD);
                 }
                 for (size_t i = 0; i < index.size(); i += 2) lists.push_back((uint32_t)index[i] | ((uint32_t)index[i + 1] << 16));
                 heads[b].first[MTJ_ROUNDS] = (int32_t)lists.size();

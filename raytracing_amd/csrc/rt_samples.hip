@@ -685,34 +685,43 @@ __global__ __launch_bounds__(256) void k_mt_emit(Dev D, uint32_t* rings, long lo
 constexpr int MTJ_RING = 4096, MTJ_CHUNK = 8 * MT_STEP;   // coefficients consumed per round
 constexpr int MTJ_ROUNDS = (19937 + MTJ_CHUNK - 1) / MTJ_CHUNK;
 // A polynomial as the list of its set coefficients (what k_mt_jump walks; pulling them out of the
-// coefficient words bit by bit cost more scalar instructions than the sums cost vector ones):
-// index[] ascending, two per 32-bit word, padded per round to a multiple of 16 with MTJ_NONE;
-// first[r] = first word of round r's coefficients (those in [r MTJ_CHUNK, (r + 1) MTJ_CHUNK)).
-constexpr uint32_t MTJ_NONE = 0xFFFFu;
+// coefficient words bit by bit cost more scalar instructions than the sums cost vector ones), made
+// so that a lane's read needs one addition: coefficient i of round r (i in [r MTJ_CHUNK,
+// (r + 1) MTJ_CHUNK)) is stored as the byte offset of s[i] in the workgroup's array, which keeps s[n]
+// at word (n - r MTJ_CHUNK + 624) & 4095 - so the words the round reads, s[i + j] for j < 624, lie
+// at offset + 4 j without wrapping.  Ascending, two per 32-bit word, padded per round to a multiple
+// of 16 with MTJ_PAD, the offset of 640 words that are kept zero.
+// first[r] = first word of round r's list.
+constexpr uint32_t MTJ_PAD = MTJ_RING * 4;
+static_assert(MTJ_CHUNK + 2 * MT_N <= MTJ_RING, "the words a round reads lie in the array without wrapping");
+static_assert(MTJ_PAD <= 0xFFFF, "offsets fit 16 bits");
 struct JumpPoly {
     int32_t first[MTJ_ROUNDS + 1];
 };
+__host__ __device__ constexpr uint32_t mtj_offset(int i, int r) { return (uint32_t)(i - r * MTJ_CHUNK + MT_N) * 4u; }
 __global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen_ends, const JumpPoly* heads, const uint32_t* lists, int level, int ell) {
-    __shared__ uint32_t xs[MTJ_RING];     // s[i] at slot i & 4095
+    __shared__ uint32_t xs[MTJ_RING + 640];     // s[n] at slot (n - c0 + 624) & 4095; the last 640 words stay zero
     typedef const __attribute__((address_space(4))) uint32_t* ConstList;   // uniform reads through the scalar unit
     const int tid = threadIdx.x;
     const int t = (1 << level) + blockIdx.x / MTJ_ROUNDS;
     const int r = blockIdx.x % MTJ_ROUNDS;          // this workgroup's share of the polynomial
     const long long L = 1ll << ell;
+    const int c0 = r * MTJ_CHUNK;
+    const int shift = MT_N - c0;                    // slot of s[n]: (n + shift) & 4095
+    xs[MTJ_RING + tid] = 0;
     // the source window: x[u L .. u L + 623] of stream u = t - 2^level, in that stream's ring
     {
         const int u = t - (1 << level);
         const long long from = (long long)u * L;
-        for (int j = tid; j < MT_N; j += 640) xs[j] = rings[(size_t)u * MT_RING + ((from + j) & (MT_RING - 1))];
+        for (int j = tid; j < MT_N; j += 640) xs[(j + shift) & (MTJ_RING - 1)] = rings[(size_t)u * MT_RING + ((from + j) & (MT_RING - 1))];
     }
     __syncthreads();
-    // s up to the last word the share reads: s[c0 + MTJ_CHUNK + 623] (the ring keeps the last 4096)
-    const int c0 = r * MTJ_CHUNK;
+    // s up to the last word the share reads: s[c0 + MTJ_CHUNK + 623] (the array keeps the last 4096)
     {
-        uint32_t prev = (tid < MT_STEP) ? xs[MT_N - MT_STEP + tid] : 0u;   // own-chain value s[gen - 227 + tid]
+        uint32_t prev = (tid < MT_STEP) ? xs[(MT_N - MT_STEP + tid + shift) & (MTJ_RING - 1)] : 0u;   // own-chain value s[gen - 227 + tid]
         for (int gen = MT_N; gen < c0 + MTJ_CHUNK + MT_N; gen += 2 * MT_STEP) {
             if (tid < MT_STEP) {
-                const int n0 = gen + tid, n1 = n0 + MT_STEP;
+                const int n0 = gen + tid + shift, n1 = n0 + MT_STEP;
                 const uint32_t x0 = prev ^ mt_twist(xs[(n0 - MT_N) & (MTJ_RING - 1)], xs[(n0 - MT_N + 1) & (MTJ_RING - 1)]);
                 const uint32_t x1 = x0 ^ mt_twist(xs[(n1 - MT_N) & (MTJ_RING - 1)], xs[(n1 - MT_N + 1) & (MTJ_RING - 1)]);
                 xs[n0 & (MTJ_RING - 1)] = x0;
@@ -725,6 +734,7 @@ __global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen
     // the share's coefficients, sixteen at a time: their reads are in flight together
     if (tid < MT_N) {
         const JumpPoly& head = heads[level];
+        const char* lane_words = reinterpret_cast<const char*>(xs + tid);
         uint32_t acc = 0;
         for (int w = head.first[r]; w < head.first[r + 1]; w += 8) {
             ConstList src = (ConstList)(uintptr_t)(lists + w);
@@ -732,10 +742,8 @@ __global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen
             uint32_t v[16];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const uint32_t i0 = packed[k] & 0xffffu, i1 = packed[k] >> 16;
-                // (a padding entry reads some word and drops it)
-                v[2 * k] = xs[(i0 + tid) & (MTJ_RING - 1)] & (i0 == MTJ_NONE ? 0u : ~0u);
-                v[2 * k + 1] = xs[(i1 + tid) & (MTJ_RING - 1)] & (i1 == MTJ_NONE ? 0u : ~0u);
+                v[2 * k] = *reinterpret_cast<const uint32_t*>(lane_words + (packed[k] & 0xffffu));
+                v[2 * k + 1] = *reinterpret_cast<const uint32_t*>(lane_words + (packed[k] >> 16));
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc ^= v[k];
