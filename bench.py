@@ -311,10 +311,7 @@ def main():
             barrier()
             t0 = time.perf_counter()
             with torch.cuda.stream(job.stream):
-                job.r.trace_checked()
-                job.r.draw_samples()
-                job.r.shade()
-                job.ctx.read_image(out=host_frame)
+                job.r.frame(out=host_frame)
             end_to_end[job.name] = (time.perf_counter() - t0) * 1e3
         del host_frame
 

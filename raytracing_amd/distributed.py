@@ -367,6 +367,29 @@ class ShardedRenderer:
             self.arena_rays *= 2
         self.collect_counts(counts)
 
+    def frame(self, out=None):
+        """One whole frame on this GPU alone (not for sharded frames): geometry, samples, lighting, the
+        image on the host (``out``: a page-locked array to read it into).  Frames without sampled
+        lights are queued as a whole and the host waits once, for the image."""
+        if self.comm.sharded:
+            raise RuntimeError("frame() renders on one GPU; sharded frames go through raytrace_sharded()")
+        if self.flat.has_sampled_lights:
+            self.trace_checked()
+            self.draw_samples()
+            self.shade()
+            return self.ctx.read_image(out=out)
+        from ._native import RtOverflow
+        while True:
+            self.begin()
+            self.trace()
+            self.shade()
+            try:
+                img = self.ctx.read_image(out=out)     # (reports the overflow too)
+                self.collect_counts(self.ctx.node_counts())
+                return img
+            except RtOverflow:
+                self.arena_rays *= 2
+
     def collect_counts(self, counts=None):
         batch, hits, beam = self.ctx.node_counts() if counts is None else counts
         self.local_batch, self.local_hits, self.local_beam = batch, hits, beam

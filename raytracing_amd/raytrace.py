@@ -144,10 +144,22 @@ class Renderer:
 
     def render_pixels(self):
         """All phases for the pixels chosen with begin_rows / begin_pixels."""
-        self.trace()
-        self.draw_samples()
-        self.shade()
-        return self.image()
+        if self.flat.has_sampled_lights:
+            self.trace()            # the host lays the sample stream out by the hit counts
+            self.draw_samples()
+            self.shade()
+            return self.image()
+        # nothing on the host depends on the counts: the whole frame is queued and the host waits
+        # once, for the image; an overflowing arena (every kernel after it does nothing) shows then
+        while True:
+            self.trace(check=False)
+            self.shade()
+            try:
+                img = self.image()           # (reports the overflow too)
+                self.node_batch, self.node_hits, self.node_beam = self.ctx.node_counts()
+                return img
+            except _native.RtOverflow:
+                self._arm(self.arena_rays * 2)
 
     # ------------------------------------------------------------------ statistics
     def counters(self):

@@ -135,6 +135,29 @@ def test_trim_gives_the_sample_work_buffers_back():
         assert np.array_equal(r.render_pixels(), first)
 
 
+def test_whole_frame_on_one_gpu_with_a_late_overflow_check():
+    """ShardedRenderer.frame(): frames without sampled lights are queued as a whole and the arena's
+    overflow flag is looked at with the image; too small an arena is doubled and the frame repeated."""
+    from raytracing_amd.distributed import Comm, ShardedRenderer
+    from raytracing_amd.raytrace import raytrace
+    for name in ("example_3", "example_4"):
+        scene = build_scene(name, 160, 90)
+        np.random.seed(4)
+        want = raytrace(scene)
+        ctx = _native.Context(0)
+        try:
+            r = ShardedRenderer(scene, None, Comm(None), ctx)
+            r.choose_rows()
+            r.arena_rays = 160 * 90 + 512
+            np.random.seed(4)
+            got = r.frame().reshape(90, 160, 3)
+            assert r.arena_rays > 160 * 90 + 512
+            assert np.array_equal(got, want)
+            assert int(r.global_hits.sum()) == ctx.counters()["hits"]
+        finally:
+            ctx.close()
+
+
 def test_samples_kept_as_raw_words_follow_every_later_call(monkeypatch):
     """Generated samples are packed as disk points only; the float64 readers (re-evaluation of hits the
     float32 pass cannot certify, the checking pass, float64 shading) take the uniforms from the raw words,
