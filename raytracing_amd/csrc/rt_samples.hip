@@ -420,6 +420,25 @@ __device__ unsigned store_map_bits(const EmitBlock* __restrict__ blocks, const i
     }
     const EmitBlock B = blocks[lo];
     if (B.light == EMIT_ALWAYS || v_first < B.off || v_last >= B.end) return 0xF;
+    // column of the step's first value (one division for the step; the waves' ranges follow by addition)
+    const long long h = B.h;
+    const long long rel = v_first - B.off;
+    long long col_first = rel - (long long)((double)rel * B.inv_h) * h;
+    if (col_first < 0) col_first += h; else if (col_first >= h) col_first -= h;
+    // does anyone read one of the n values from v on?  (columns [col, col + n), beyond h on the next row from column 0)
+    auto read_by_someone = [&](long long v, long long n) -> bool {
+        if (n >= h) return true;
+        long long col = col_first + (v - v_first);
+        while (col >= h) col -= h;
+        for (int part = 0; part < 2; ++part) {
+            long long c0 = part == 0 ? col : 0, c1 = part == 0 ? min(col + n, h) : col + n - h;
+            c0 = max(c0, (long long)B.first_col) - B.first_col;
+            c1 = min(c1, (long long)B.first_col + B.mine) - B.first_col;
+            if (c0 < c1 && any_mask_bits(mask, (unsigned long long)B.word0 * 64 + c0, (unsigned long long)B.word0 * 64 + c1)) return true;
+        }
+        return false;
+    };
+    if (!read_by_someone(v_first, v_last - v_first + 1)) return 0;   // two steps in three
     unsigned bits = 0;
     for (int w = 0; w < 4; ++w) {
         const long long wa = w_first + 64 * w, wb = wa + (w == 3 ? MT_STEP - 192 : 64);   // [wa, wb)
@@ -427,21 +446,7 @@ __device__ unsigned store_map_bits(const EmitBlock* __restrict__ blocks, const i
         const long long va = wa >= pos ? (wa - pos) >> 1 : 0;
         const long long vb = min((wb - 1 - pos) >> 1, n_values - 1);
         if (va > vb) continue;
-        const long long n = vb - va + 1;
-        if (n >= (long long)B.h) { bits |= 1u << w; continue; }
-        const long long rel = va - B.off;
-        long long row = (long long)((double)rel * B.inv_h);
-        long long col = rel - row * (long long)B.h;
-        if (col < 0) col += B.h; else if (col >= (long long)B.h) col -= B.h;
-        // columns [col, col + n), the part beyond h on the next row from column 0
-        bool any = false;
-        for (int part = 0; part < 2 && !any; ++part) {
-            long long c0 = part == 0 ? col : 0, c1 = part == 0 ? min(col + n, (long long)B.h) : col + n - (long long)B.h;
-            c0 = max(c0, (long long)B.first_col) - B.first_col;
-            c1 = min(c1, (long long)B.first_col + B.mine) - B.first_col;
-            if (c0 < c1) any = any_mask_bits(mask, (unsigned long long)B.word0 * 64 + c0, (unsigned long long)B.word0 * 64 + c1);
-        }
-        if (any) bits |= 1u << w;
+        if (read_by_someone(va, vb - va + 1)) bits |= 1u << w;
     }
     return bits;
 }
