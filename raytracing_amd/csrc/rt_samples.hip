@@ -240,9 +240,14 @@ __global__ __launch_bounds__(256) void k_mt_generate(uint32_t* rings, long long*
     ConstMap need_t = need ? (ConstMap)(uintptr_t)(need + (size_t)t * need_words) : nullptr;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t* lane_ring = ring + tid;
-    uint32_t* out_it = out + rel_first;                   // the iteration's first word in out[] (uniform)
-    auto iteration = [&](int it, unsigned both) {
-        if (lane_on) {
+    // (the loop is bound by the scalar unit, one per compute unit and shared by every wave on it: the common
+    // iteration - all of its words have a place in out[] - is kept free of 64-bit counters and range tests)
+    char* const out_bytes = reinterpret_cast<char*>(out);
+    uint32_t lane_out = (uint32_t)((rel_first + tid) * 4);   // byte offset of the lane's first word of the iteration in out[] (used while it is inside)
+    // CHECKED: some of the iteration's words may have no place in out[] (a stream's first and last iterations)
+    // whole: every lane of the wave computes (the first three waves; the fourth has 35 lanes that do)
+    auto iteration = [&](auto checked, auto whole, int it, bool store0, bool store1) {
+        if (decltype(whole)::value || lane_on) {
             const uint32_t* operands = lane_ring + ((base - MT_N) & (MT_RING - 1));
             const uint32_t lo0 = operands[0], hi0 = operands[1], lo1 = operands[MT_STEP], hi1 = operands[MT_STEP + 1];
             const uint32_t x0 = prev ^ mt_twist(lo0, hi0);
@@ -250,30 +255,48 @@ __global__ __launch_bounds__(256) void k_mt_generate(uint32_t* rings, long long*
             const int s0 = (base + tid) & (MT_RING - 1), s1 = (base + tid + MT_STEP) & (MT_RING - 1);
             ring[s0] = x0; ring[s0 + MT_RING] = x0;
             ring[s1] = x1; ring[s1 + MT_RING] = x1;
-            if (it >= full_lo && it < full_hi) {
-                if (both & 1u) out_it[tid] = x0;
-                if (both & 0x100u) out_it[tid + MT_STEP] = x1;
+            if constexpr (!decltype(checked)::value) {
+                if (store0) *reinterpret_cast<uint32_t*>(out_bytes + lane_out) = x0;
+                if (store1) *reinterpret_cast<uint32_t*>(out_bytes + lane_out + 4 * MT_STEP) = x1;
             } else {
                 const long long rel = rel_first + (long long)it * (2 * MT_STEP) + tid;
-                if ((both & 1u) && rel >= 0 && rel < raw_n) out[rel] = x0;
-                if ((both & 0x100u) && rel + MT_STEP >= 0 && rel + MT_STEP < raw_n) out[rel + MT_STEP] = x1;
+                if (store0 && rel >= 0 && rel < raw_n) out[rel] = x0;
+                if (store1 && rel + MT_STEP >= 0 && rel + MT_STEP < raw_n) out[rel + MT_STEP] = x1;
             }
             prev = x1;
         }
+        lane_out += 4 * 2 * MT_STEP;
         base = (base + 2 * MT_STEP) & (MT_RING - 1);
-        out_it += 2 * MT_STEP;
         __syncthreads();
     };
-    for (int it0 = 0; it0 < iters; it0 += 4 * MAP_GROUP) {
-        unsigned long long map[MAP_GROUP];
-#pragma unroll
-        for (int q = 0; q < MAP_GROUP; ++q) map[q] = need_t ? need_t[min(it0 / 4 + q, need_words - 1)] : ~0ull;
-#pragma unroll
-        for (int q = 0; q < MAP_GROUP; ++q) {
-            const int n = min(4, iters - it0 - 4 * q);
-            for (int r = 0; r < n; ++r) iteration(it0 + 4 * q + r, (unsigned)(map[q] >> (r * 16 + wave)));
+    int it = 0;
+    auto checked_until = [&](int end) {
+        for (; it < end; ++it) {
+            const unsigned long long word = need_t ? need_t[min(it >> 2, need_words - 1)] : ~0ull;
+            const unsigned both = (unsigned)(word >> ((it & 3) * 16 + wave));
+            iteration(std::true_type{}, std::false_type{}, it, both & 1u, both & 0x100u);
         }
-    }
+    };
+    // whole map words (four iterations each) of iterations that are inside: [main_lo, main_hi)
+    const int main_lo = min(iters, (full_lo + 3) & ~3), main_hi = max(main_lo, full_hi & ~3);
+    checked_until(main_lo);
+    auto main_loop = [&](auto whole) {
+        for (; it < main_hi; it += 4 * MAP_GROUP) {
+            unsigned long long map[MAP_GROUP];
+#pragma unroll
+            for (int q = 0; q < MAP_GROUP; ++q) map[q] = need_t ? need_t[min(it / 4 + q, need_words - 1)] : ~0ull;
+#pragma unroll
+            for (int q = 0; q < MAP_GROUP; ++q) {
+                if (it + 4 * q >= main_hi) break;
+                const unsigned long long m = map[q] >> wave;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) iteration(std::false_type{}, whole, 0, (m >> (16 * r)) & 1u, (m >> (16 * r + 8)) & 1u);
+            }
+        }
+    };
+    if (wave < MT_STEP / 64) main_loop(std::true_type{}); else main_loop(std::false_type{});   // (both take every barrier)
+    it = main_hi;
+    checked_until(iters);
     for (int i = tid; i < MT_RING; i += 256) ring_g[i] = ring[i];
     if (tid == 0) gen_ends[t] = g0 + (long long)iters * 2 * MT_STEP;
 }
