@@ -17,6 +17,9 @@ namespace rt {
 struct UploadedStream {
     static constexpr bool WHOLE_IMAGE = false;   // positions are in this context's own stream
     const double* chunk;   // chunk[i] = stream[a + i]
+    typedef double Raw;    // what is loaded for a value, and the value it becomes
+    __device__ __forceinline__ Raw load(int64_t i) const { return chunk[i]; }
+    static __device__ __forceinline__ double value(Raw r) { return r; }
     __device__ __forceinline__ double operator()(int64_t i) const { return chunk[i]; }
 };
 // ... or raw MT19937 state words made on the device: value i of the piece is built from words
@@ -32,10 +35,13 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 struct GeneratedStream {
     static constexpr bool WHOLE_IMAGE = true;    // positions are in the whole image's stream when the layout says so
     const uint32_t* raw;   // raw[2 i], raw[2 i + 1]: untempered words of stream[a + i]
-    __device__ __forceinline__ double operator()(int64_t i) const {
-        const uint32_t hi = mt_temper(raw[2 * i]) >> 5, lo = mt_temper(raw[2 * i + 1]) >> 6;
+    typedef uint2 Raw;
+    __device__ __forceinline__ Raw load(int64_t i) const { return make_uint2(raw[2 * i], raw[2 * i + 1]); }
+    static __device__ __forceinline__ double value(Raw r) {
+        const uint32_t hi = mt_temper(r.x) >> 5, lo = mt_temper(r.y) >> 6;
         return ((double)hi * 67108864.0 + (double)lo) / 9007199254740992.0;
     }
+    __device__ __forceinline__ double operator()(int64_t i) const { return value(load(i)); }
 };
 
 // The point of the unit disk a pair of uniforms selects, as the float32 sample pass reads it
@@ -88,7 +94,7 @@ __device__ __forceinline__ SampleColumn sample_column(const Dev& D, int64_t e, i
 // need not read the packed uniforms again.  with_points == 2: only the points - the float64 readers
 // (the re-evaluation of uncertified hits) take their uniforms from the raw words, Dev::raw_values_at.
 template <typename Stream>
-__global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, int64_t n, int with_points) {
+__global__ __launch_bounds__(BLOCK, RT_PACK_WAVES) void k_pack(Dev D, Stream chunk, int64_t a, int64_t n, int with_points) {
     const SceneConst& sc = *D.sc;
     const int64_t b = a + n;
     const int64_t E = D.pack_E;
@@ -115,12 +121,28 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, 
                 // both uniforms of a sample together: packed as below, and the point they select
                 const int NP = (N + 1) >> 1;
                 float4* points = reinterpret_cast<float4*>(D.packed32) + D.pack32_base[l] + (e / TILE) * NP * TILE + (e % TILE);
-                for (int p = 0; p < NP; ++p) {
+                // (the rows of a column lie far apart in the stream: the loads of the next pair are in
+                // flight while the current one goes through sincospi and sqrt; two register sets in turn,
+                // no loaded register is copied)
+                typedef typename Stream::Raw Raw;
+                struct Pair { Raw angle[2], radius[2]; };
+                auto fetch = [&](int p, Pair& q) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int s = 2 * p + k;
+                        if (s < N && c.any) {
+                            q.angle[k] = chunk.load(c.first + s * c.h - a);
+                            q.radius[k] = chunk.load(c.first + ((int64_t)N + s) * c.h - a);
+                        }
+                    }
+                };
+                auto emit = [&](int p, const Pair& q) {
                     float x[2] = {0, 0}, y[2] = {0, 0};
+#pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int s = 2 * p + k;
                         if (s >= N || !c.any) break;
-                        const double u_angle = chunk(c.first + s * c.h - a), u_radius = chunk(c.first + ((int64_t)N + s) * c.h - a);
+                        const double u_angle = Stream::value(q.angle[k]), u_radius = Stream::value(q.radius[k]);
                         if (with_points != 2) {
                             dst[s * E] = u_angle;
                             dst[D.pack_plane + s * E] = u_radius;
@@ -128,6 +150,14 @@ __global__ __launch_bounds__(BLOCK) void k_pack(Dev D, Stream chunk, int64_t a, 
                         disk_point(u_angle, u_radius, x[k], y[k]);
                     }
                     points[(int64_t)p * TILE] = make_float4(x[0], x[1], y[0], y[1]);
+                };
+                Pair qa{}, qb{};
+                fetch(0, qa);
+                for (int p = 0; p < NP; p += 2) {
+                    if (p + 1 < NP) fetch(p + 1, qb);
+                    emit(p, qa);
+                    if (p + 2 < NP) fetch(p + 2, qa);
+                    if (p + 1 < NP) emit(p + 1, qb);
                 }
                 continue;
             }
