@@ -1249,6 +1249,8 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     }
     ctx->mt_raw.transient = true;
     if (!fused) HIP_TRY(ctx->mt_raw.ensure((size_t)per_pass * L + 2));
+    // (tests of the store map: what the generator leaves out must not happen to hold an earlier call's words)
+    if (!fused && getenv("RT_MT_POISON")) HIP_TRY(hipMemsetAsync(ctx->mt_raw.p, 0xA5, ctx->mt_raw.n * sizeof(uint32_t), ctx->stream));
     // The state NumPy would be left in: the key block that holds the last word consumed and
     // the position after it (a position of 624 means "regenerate at the next draw").
     const long long block = (next - 1) / MT_N;

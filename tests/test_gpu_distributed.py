@@ -32,6 +32,7 @@ def _watchdog(seconds=240):
 
 def _worker(rank, world, port, name, w, h, out_path, precision="mixed"):
     _watchdog()
+    os.environ["RT_MT_POISON"] = "1"    # raw words the generator does not store hold a pattern, not an earlier frame's values
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -491,6 +491,7 @@ def test_device_mt19937_store_map(monkeypatch, store_all, max_streams):
     equals the one from host-drawn samples and the stream ends in the same place.  The spotlight's
     blocks are not screened (in-beam numbering) and lie between screened ones."""
     from raytracing_amd import objects
+    monkeypatch.setenv("RT_MT_POISON", "1")     # words the generator leaves out hold a pattern, not an earlier frame's values
     for name, value in (("RT_MT_STORE_ALL", "1" if store_all else None), ("RT_MT_MAX_STREAMS", max_streams)):
         if value is None:
             monkeypatch.delenv(name, raising=False)
@@ -498,7 +499,9 @@ def test_device_mt19937_store_map(monkeypatch, store_all, max_streams):
             monkeypatch.setenv(name, str(value))
     spot_scene = synthetic.spotlight_scene("linear", 16, 200, 112)
     spot_scene.light_sources = [objects.DiskSource(x=-3, y=1, z=6, radius=1.5, intensity=20, N=5)] + list(spot_scene.light_sources)
-    for scene in (build_scene("example_4", 480, 270), spot_scene):
+    crowd = _disk_scene(97, 41, extra_spheres=12, n_points=9)                 # many nodes with few hits: narrow blocks
+    crowd_spot = _disk_scene(120, 67, extra_spheres=37, spot=True, n_points=5)
+    for scene in (build_scene("example_4", 480, 270), spot_scene, crowd, crowd_spot):
         np.random.seed(99)
         st = np.random.get_state()
         st = (st[0], st[1], 5) + tuple(st[3:])
