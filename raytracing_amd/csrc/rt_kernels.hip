@@ -40,7 +40,7 @@
 #define RT_SURFACE_WAVES 2   // waves per SIMD requested for the float64 lighting kernel (few spheres)
 #endif
 #ifndef RT_PACK_WAVES
-#define RT_PACK_WAVES 4   // waves per SIMD requested for k_pack (4K example_4 end to end: 2: 27.1 ms, 3: 27.0, 4: 26.7, 5: 28.3, 6: 31.7)
+#define RT_PACK_WAVES 3   // waves per SIMD requested for k_pack (4K example_4 end to end: 2: 27.1 ms, 3: 27.0, 4: 26.7 but with 80 bytes of spilled registers per lane and 5 GB more traffic, 5: 28.3, 6: 31.7)
 #endif
 #ifndef RT_SURFACE_WAVES_MANY
 #define RT_SURFACE_WAVES_MANY 3   // waves per SIMD requested for the many-sphere variant of k_surface (measured with the grid and the light maps, 4096 spheres at 4K: 2: 24.7 ms, 3: 24.6, 4: 27.0, 6: 41.8, 8: 54.6)
