@@ -225,7 +225,7 @@ struct RtContext {
     DevBuf<long long> mt_end;
     DevBuf<unsigned long long> mt_need;     // store map of the generator (k_store_map)
     DevBuf<unsigned long long> mt_stat;
-    std::vector<int32_t> node_hits_host;    // the hits per node as rt_get_node_counts last read them ...
+    std::vector<int32_t> node_hits_host, node_beam_host;   // the hits (in-beam hits) per node as rt_get_node_counts last read them ...
     bool node_hits_host_valid = false;      // ... and no level 0 has been traced since
     int mt_polys_ell = -1, mt_polys_n = 0;  // what mt_polys holds: the polynomials x^(2^(ell + b)), b < n
     long long generator_words = 0, generator_words_stored = 0;   // of the last rt_generate_samples
@@ -908,6 +908,7 @@ int rt_get_node_counts(RtContext* ctx, int64_t* batch, int64_t* hits, int64_t* b
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (flag) return fail(RT_ERR_OVERFLOW, "ray arena of %lld rays is too small for this frame", (long long)ctx->arena_rays);
     ctx->node_hits_host = h;   // rt_generate_samples needs them again
+    ctx->node_beam_host = bm;
     ctx->node_hits_host_valid = true;
     for (int k = 0; k < K; ++k) {
         if (batch) batch[k] = n[k];
@@ -1177,36 +1178,47 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
     std::vector<EmitBlock> blocks;
     if (fused || mapped) {
         const int K = ctx->tree.n_nodes(), Lv = ctx->tree.n_levels();
-        std::vector<int32_t> hits(K), shade_base(Lv + 1, 0);
+        std::vector<int32_t> hits(K), beam((size_t)K * RT_MAX_LIGHTS, 0), shade_base(Lv + 1, 0);
         std::vector<uint32_t> pre((size_t)K * NCNT, 0u);
-        if (mapped && ctx->node_hits_host_valid && (int)ctx->node_hits_host.size() == K) {
-            hits = ctx->node_hits_host;          // the map only needs the hits per node, and the host has read them
+        if (mapped && ctx->node_hits_host_valid && (int)ctx->node_hits_host.size() == K && ctx->node_beam_host.size() == beam.size()) {
+            hits = ctx->node_hits_host;          // the map only needs the counts per node, and the host has read them
+            beam = ctx->node_beam_host;
         } else {
             HIP_TRY(hipMemcpyAsync(hits.data(), ctx->node_hits.p, (size_t)K * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(beam.data(), ctx->node_beam.p, beam.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipMemcpyAsync(shade_base.data(), ctx->lvl_shade_base.p, (size_t)(Lv + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipMemcpyAsync(pre.data(), ctx->node_pre.p, pre.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
-        word0.assign(K + 1, 0u);
-        for (int k = 0; k < K; ++k) word0[k + 1] = word0[k] + (uint32_t)((hits[k] + 63) / 64);
+        // The mask has one row of bits per way of numbering hits: row 0 all hits of a node (the columns of a disk
+        // light's blocks), row 1 + l the hits inside spotlight l's beam (the columns of its blocks); node k's bits of
+        // a row start at 64-bit word word0[row * (K + 1) + k].
+        const int n_lights = ctx->sc_host.n_lights;
+        const size_t row_len = (size_t)K + 1;
+        word0.assign((1 + RT_MAX_LIGHTS) * row_len, 0u);
+        uint32_t mask_words = 0;
+        bool row_used[1 + RT_MAX_LIGHTS] = {ctx->disk_lights};
+        for (int l = 0; l < n_lights; ++l) row_used[1 + l] = mapped && ((ctx->spot_mask >> l) & 1u);
+        for (int row = 0; row <= RT_MAX_LIGHTS; ++row) {
+            for (int k = 0; k < K; ++k) {
+                word0[row * row_len + k] = mask_words;
+                const int32_t count = row == 0 ? hits[k] : beam[(size_t)k * RT_MAX_LIGHTS + row - 1];
+                if (row_used[row]) mask_words += (uint32_t)((count + 63) / 64);
+            }
+            word0[row * row_len + K] = mask_words;
+        }
         const bool whole = ctx->have_global_layout;
         const size_t KL = (size_t)K * RT_MAX_LIGHTS;
         for (int k = 0; k < K; ++k)
-            for (int l = 0; l < ctx->sc_host.n_lights; ++l) {
+            for (int l = 0; l < n_lights; ++l) {
+                const int kind = ctx->sc_host.lights[l].kind;
+                if (kind != RT_LIGHT_DISK && !(kind == RT_LIGHT_SPOT && mapped)) continue;
                 const size_t at = (size_t)k * RT_MAX_LIGHTS + l;
+                const int row = kind == RT_LIGHT_SPOT ? 1 + l : 0;
                 const int64_t off = whole ? ctx->sample_global_host[at] : ctx->sample_off_host[at];
-                if (ctx->sc_host.lights[l].kind == RT_LIGHT_SPOT && mapped && off >= 0) {
-                    // values in the beam's own numbering: every word of the block is stored (its end: the next block's offset)
-                    EmitBlock b{};
-                    b.off = off;
-                    b.end = -1;
-                    b.light = EMIT_ALWAYS;
-                    blocks.push_back(b);
-                    continue;
-                }
-                if (ctx->sc_host.lights[l].kind != RT_LIGHT_DISK) continue;
-                const int64_t h = whole ? ctx->sample_global_host[KL + at] : hits[k];
-                if (off < 0 || h <= 0 || (fused && hits[k] <= 0)) continue;
+                const int32_t mine = row == 0 ? hits[k] : beam[at];
+                const int64_t h = whole ? ctx->sample_global_host[KL + at] : mine;
+                if (off < 0 || h <= 0 || (fused && mine <= 0)) continue;
                 // shaded hits of the node: the level-wide running count at the next node's first tile minus its own
                 const int lv = ctx->tree.level[k];
                 const uint32_t upto = k + 1 < ctx->tree.level_start[lv + 1] ? pre[(size_t)(k + 1) * NCNT + C_SHADE]
@@ -1219,30 +1231,32 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
                 b.h = (uint32_t)h;
                 b.inv_h = 1.0 / (double)h;
                 b.first_col = whole ? (uint32_t)ctx->sample_global_host[2 * KL + at] : 0u;
-                b.mine = (uint32_t)hits[k];
-                b.word0 = word0[k];
-                b.e_first = (uint32_t)shade_base[ctx->tree.level[k]] + pre[(size_t)k * NCNT + C_SHADE];
+                b.mine = (uint32_t)mine;
+                b.word0 = word0[row * row_len + k];
+                b.e_first = (uint32_t)shade_base[ctx->tree.level[k]] + pre[(size_t)k * NCNT + C_SHADE];   // (the fused generator's)
                 b.light = (uint32_t)l;
                 blocks.push_back(b);
             }
         std::sort(blocks.begin(), blocks.end(), [](const EmitBlock& a, const EmitBlock& b) { return a.off < b.off; });
         n_emit_blocks = (int)blocks.size();
-        for (int i = 0; i < n_emit_blocks; ++i)
-            if (blocks[i].light == EMIT_ALWAYS) blocks[i].end = i + 1 < n_emit_blocks ? blocks[i + 1].off : (int64_t)total;
         fused = fused && n_emit_blocks > 0;
         mapped = mapped && n_emit_blocks > 0;
         if (fused || mapped) {
             ctx->hit_mask.transient = ctx->hit_pref.transient = true;
             HIP_TRY(ctx->hit_word0.ensure(word0.size()));
             HIP_TRY(ctx->emit_blocks.ensure(blocks.size()));
-            HIP_TRY(ctx->hit_mask.ensure((size_t)word0[K] + 2));
-            if (fused) HIP_TRY(ctx->hit_pref.ensure((size_t)word0[K] + 2));
+            HIP_TRY(ctx->hit_mask.ensure((size_t)mask_words + 2));
+            if (fused) HIP_TRY(ctx->hit_pref.ensure((size_t)mask_words + 2));
             HIP_TRY(hipMemcpyAsync(ctx->hit_word0.p, word0.data(), word0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(hipMemcpyAsync(ctx->emit_blocks.p, blocks.data(), blocks.size() * sizeof(EmitBlock), hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(hipMemsetAsync(ctx->hit_mask.p, 0, ((size_t)word0[K] + 2) * 8, ctx->stream));
+            HIP_TRY(hipMemsetAsync(ctx->hit_mask.p, 0, ((size_t)mask_words + 2) * 8, ctx->stream));
             const Dev Dm = ctx->dev();
-            for (int level = 0; level < Lv; ++level)
-                hipLaunchKernelGGL(k_hitmask, dim3(ctx->nb), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, Dm, level, ctx->hit_word0.p, ctx->hit_mask.p);
+            for (int row = 0; row <= RT_MAX_LIGHTS; ++row) {
+                if (!row_used[row]) continue;
+                for (int level = 0; level < Lv; ++level)
+                    hipLaunchKernelGGL(k_hitmask, dim3(ctx->nb), dim3(BLOCK), level_table_bytes(ctx, level), ctx->stream, Dm, level,
+                                       ctx->hit_word0.p + row * row_len, ctx->hit_mask.p, row == 0 ? (int)C_HIT : (int)C_BEAM0 + row - 1);
+            }
             if (fused) hipLaunchKernelGGL(k_hitprefix, dim3(K), dim3(BLOCK), 0, ctx->stream, ctx->hit_mask.p, ctx->hit_word0.p, ctx->hit_pref.p);
             HIP_TRY(hipGetLastError());
         }

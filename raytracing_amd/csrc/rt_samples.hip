@@ -356,8 +356,10 @@ struct EmitBlock {
 static_assert(sizeof(EmitBlock) == 56, "EmitBlock is read as seven 8-byte words");
 
 // One bit per hit, in node order then pixel order: set if the hit is on the shading list.  One launch
-// per level, the grid and the tile runs of k_link.  mask must be zero on entry.
-__global__ __launch_bounds__(BLOCK) void k_hitmask(Dev D, int level, const uint32_t* __restrict__ node_word0, unsigned long long* mask) {
+// per level, the grid and the tile runs of k_link.  mask must be zero on entry.  counter: C_HIT - all
+// hits, the columns of a disk light's sample blocks - or C_BEAM0 + l: the hits inside spotlight l's beam,
+// the columns of its blocks.
+__global__ __launch_bounds__(BLOCK) void k_hitmask(Dev D, int level, const uint32_t* __restrict__ node_word0, unsigned long long* mask, int counter) {
     extern __shared__ int s_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (D.flags[0]) return;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void k_hitmask(Dev D, int level, const uint3
     const int t_end = min(nt, t_begin + q);
     if (blockIdx.x * WPB * q >= nt) return;
     const LevelTables T = stage_level_tables(D, level, s_dyn, tid, blockIdx.x * WPB * q, min(nt, (int)(blockIdx.x + 1) * WPB * q) - 1);
-    const unsigned wave_base = D.blk_tot[((size_t)level * NCNT + C_HIT) * NB + blockIdx.x] + D.wave_off[((size_t)level * NCNT + C_HIT) * NW + wid];
+    const unsigned wave_base = D.blk_tot[((size_t)level * NCNT + counter) * NB + blockIdx.x] + D.wave_off[((size_t)level * NCNT + counter) * NW + wid];
     __syncthreads();
     int kk = (t_begin < t_end) ? find_node(T.node, nn, t_begin) : 0;
     for (int t = t_begin; t < t_end; ++t) {
@@ -380,17 +382,18 @@ __global__ __launch_bounds__(BLOCK) void k_hitmask(Dev D, int level, const uint3
         const int first = (t - __builtin_amdgcn_readfirstlane(r.tile0)) * TILE;
         const int cnt = min(TILE, __builtin_amdgcn_readfirstlane(r.n) - first);
         const uint32_t info = lane < cnt ? D.info[(uint32_t)(tbase + t) * TILE + lane] : I_NO_HIT;
-        const unsigned long long hits = __ballot(is_hit(info));
+        const bool mine = counted(info, counter);
+        const unsigned long long hits = __ballot(mine);
         if (hits == 0) continue;
-        const unsigned trun = D.tile_run[(size_t)(tbase + t) * NCNT + C_HIT];
+        const unsigned trun = D.tile_run[(size_t)(tbase + t) * NCNT + counter];
         // shade bits in hit order: hit number i of the tile sends its bit to lane i
         const int nh = __popcll(hits);
-        const int dest = is_hit(info) ? lanes_below(hits) : 63;
+        const int dest = mine ? lanes_below(hits) : 63;
         const int got = __builtin_amdgcn_ds_permute(dest * 4, (info & I_SHADE) ? 1 : 0);
         unsigned long long bits = __ballot(got != 0);
         if (nh < 64) bits &= (1ull << nh) - 1;
         // rank of the tile's first hit inside its node -> place in the mask
-        const unsigned long long place = (unsigned long long)node_word0[k0 + kk] * 64 + (wave_base + trun - T.pre[kk * 16 + C_HIT]);
+        const unsigned long long place = (unsigned long long)node_word0[k0 + kk] * 64 + (wave_base + trun - T.pre[kk * 16 + counter]);
         const unsigned sh = (unsigned)(place & 63);
         if (lane == 0 && bits != 0) {
             atomicOr(&mask[place >> 6], bits << sh);
@@ -431,10 +434,11 @@ __global__ __launch_bounds__(BLOCK) void k_hitprefix(const unsigned long long* _
 // runs, since hits are numbered in pixel order and surfaces without a diffuse part cover areas.  The
 // generator stores a step's 227 words wave by wave (64 + 64 + 64 + 35); the map has one byte per step,
 // bit w set if wave w's words hold part of a value somebody reads (conservative: whenever that is
-// not cheap to tell - a run of values across two (node, light) blocks, a spotlight's block - the bit is
-// set).  One thread per step; steps are counted from word t L + 624 of stream t, where an unused
+// not cheap to tell - a run of values across two (node, light) blocks, a block narrower than the run -
+// the bit is set).  A spotlight's columns are the hits inside its beam, a disk light's all hits of the
+// node: the mask has a row of bits for each numbering (k_hitmask's counter).  One thread per step; steps are counted from word t L + 624 of stream t, where an unused
 // stream starts generating.
-//   blocks      every (node, light) block with values, sorted by offset; light == EMIT_ALWAYS: no mask
+//   blocks      every (node, light) block with values, sorted by offset (light == EMIT_ALWAYS: a block without a mask)
 //   need        [streams][bytes_per_stream] bytes (bytes_per_stream a multiple of 8)
 //   words_kept  += the words the map lets the generator store
 constexpr uint32_t EMIT_ALWAYS = 0xFFFFFFFFu;
