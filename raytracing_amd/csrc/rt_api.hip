@@ -225,6 +225,9 @@ struct RtContext {
     DevBuf<long long> mt_end;
     DevBuf<unsigned long long> mt_need;     // store map of the generator (k_store_map)
     DevBuf<unsigned long long> mt_stat;
+    DevBuf<uint32_t> mt_ring0;              // the streams' start windows, kept while a stream is made in passes of whole blocks
+    DevBuf<long long> mt_end0;
+    DevBuf<uint8_t> pass_of;                // [node][light]: the pass that holds the block
     std::vector<int32_t> node_hits_host, node_beam_host;   // the hits (in-beam hits) per node as rt_get_node_counts last read them ...
     bool node_hits_host_valid = false;      // ... and no level 0 has been traced since
     int mt_polys_ell = -1, mt_polys_n = 0;  // what mt_polys holds: the polynomials x^(2^(ell + b)), b < n
@@ -541,6 +544,7 @@ void rt_destroy(RtContext* ctx) {
     ctx->X.release(); ctx->Y.release(); ctx->packed.release(); ctx->packed32.release(); ctx->staging.release();
     ctx->image.release(); ctx->image8.release(); ctx->mt_ring.release(); ctx->mt_raw.release(); ctx->mt_polys.release(); ctx->mt_end.release(); ctx->sample_off.release(); ctx->sample_global.release(); ctx->hit_mask.release(); ctx->hit_pref.release(); ctx->hit_word0.release(); ctx->emit_blocks.release(); ctx->work.release();
     ctx->mt_need.release(); ctx->mt_stat.release(); ctx->raw_slot.release();
+    ctx->mt_ring0.release(); ctx->mt_end0.release(); ctx->pass_of.release();
     if (ctx->bounce) (void)hipHostFree(ctx->bounce);
     for (auto e : ctx->bounce_done) if (e) (void)hipEventDestroy(e);
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
@@ -992,7 +996,7 @@ static int materialize_packed(RtContext* ctx) {
         const long long total = ctx->have_global_layout ? ctx->global_total : ctx->sample_total;
         const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB));
         hipLaunchKernelGGL((k_pack<GeneratedStream>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(),
-                           GeneratedStream{ctx->mt_raw.p + ctx->raw_value0}, (int64_t)0, (int64_t)total, 0);
+                           GeneratedStream{ctx->mt_raw.p + ctx->raw_value0}, (int64_t)0, (int64_t)total, 0, nullptr, 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemsetAsync(ctx->raw_slot.p, 0, sizeof(const uint32_t*), ctx->stream));
@@ -1014,7 +1018,7 @@ int rt_upload_samples(RtContext* ctx, int64_t dst_offset, const double* u, int64
     if (ctx->pack_E > 0) {
         const int64_t blocks = std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB);
         hipLaunchKernelGGL((k_pack<UploadedStream>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(),
-                           UploadedStream{ctx->staging.p}, dst_offset, n, 0);
+                           UploadedStream{ctx->staging.p}, dst_offset, n, 0, nullptr, 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller
@@ -1042,7 +1046,7 @@ int rt_upload_samples_noalloc(RtContext* ctx, int64_t dst_offset, const double* 
     if (ctx->pack_E > 0) {
         const int64_t blocks = std::min<int64_t>((ctx->pack_E + BLOCK - 1) / BLOCK, 4 * NB);
         hipLaunchKernelGGL((k_pack<UploadedStream>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->dev(),
-                           UploadedStream{staging}, dst_offset, n, 0);
+                           UploadedStream{staging}, dst_offset, n, 0, nullptr, 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // u may be reused by the caller, the array by the next call
@@ -1249,6 +1253,7 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
                 b.word0 = word0[row * row_len + k];
                 b.e_first = (uint32_t)shade_base[ctx->tree.level[k]] + pre[(size_t)k * NCNT + C_SHADE];   // (the fused generator's)
                 b.light = (uint32_t)l;
+                b.node = (uint32_t)k;
                 blocks.push_back(b);
             }
         std::sort(blocks.begin(), blocks.end(), [](const EmitBlock& a, const EmitBlock& b) { return a.off < b.off; });
@@ -1302,7 +1307,57 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
                            (long long)pos, total, ell, steps_per_stream, need_words * 8, n_bytes, reinterpret_cast<uint8_t*>(ctx->mt_need.p), ctx->mt_stat.p);
     }
     bool points_made = false, raw_only = false;
-    for (int t0 = 0; t0 < T && !fused; t0 += per_pass) {
+    // Several passes, frame shaded in mixed precision: the passes are made of whole (node, light) blocks, so that
+    // every block's samples are complete within its pass and k_pack makes their disk points on the way, as in
+    // the single pass.  The streams at a pass's ends are generated again by its neighbour, from a copy of the start
+    // windows.  (RT_MT_RANGE_PASSES=1, or a block that no pass holds: passes by ranges of the stream, uniforms
+    // only, the points afterwards.)
+    struct BlockPass { int t0, n_streams; };
+    std::vector<BlockPass> block_passes;
+    std::vector<uint8_t> pass_of;
+    if (!fused && mapped && per_pass < T && ctx->pack_E > 0 && ctx->have_packed32 && ctx->precision != RT_PRECISION_F64 && !getenv("RT_MT_RANGE_PASSES")) {
+        pass_of.assign((size_t)ctx->tree.n_nodes() * RT_MAX_LIGHTS, 0xFF);
+        for (const EmitBlock& b : blocks) {
+            const long long first_word = (long long)pos + 2 * b.off, last_word = (long long)pos + 2 * b.end - 1;
+            const int ta = (int)std::max(0ll, (first_word - 1) >> ell), tb = (int)std::min<long long>(T - 1, last_word >> ell);
+            if (block_passes.empty() || tb - block_passes.back().t0 + 1 > per_pass) block_passes.push_back({ta, 0});
+            BlockPass& P = block_passes.back();
+            P.n_streams = std::max(P.n_streams, tb - P.t0 + 1);
+            if (P.n_streams > per_pass || block_passes.size() > 250) {   // a block larger than the buffer
+                block_passes.clear();
+                break;
+            }
+            pass_of[(size_t)b.node * RT_MAX_LIGHTS + b.light] = (uint8_t)(block_passes.size() - 1);
+        }
+    }
+    if (!block_passes.empty()) {
+        ctx->mt_ring0.transient = true;
+        HIP_TRY(ctx->mt_ring0.ensure((size_t)T * MT_RING));
+        HIP_TRY(ctx->mt_end0.ensure((size_t)T));
+        HIP_TRY(ctx->pass_of.ensure(pass_of.size()));
+        HIP_TRY(hipMemcpyAsync(ctx->pass_of.p, pass_of.data(), pass_of.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->mt_ring0.p, ctx->mt_ring.p, (size_t)T * MT_RING * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->mt_end0.p, ctx->mt_end.p, (size_t)T * sizeof(long long), hipMemcpyDeviceToDevice, ctx->stream));
+        for (size_t p = 0; p < block_passes.size(); ++p) {
+            const int t0 = block_passes[p].t0, n_streams = block_passes[p].n_streams;
+            if (p > 0) {   // (the first streams may have run in the pass before)
+                HIP_TRY(hipMemcpyAsync(ctx->mt_ring.p + (size_t)t0 * MT_RING, ctx->mt_ring0.p + (size_t)t0 * MT_RING,
+                                       (size_t)n_streams * MT_RING * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(hipMemcpyAsync(ctx->mt_end.p + t0, ctx->mt_end0.p + t0, (size_t)n_streams * sizeof(long long), hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            const long long w_lo = (long long)t0 << ell, w_first = w_lo + (t0 > 0 ? 1 : 0);
+            const long long w_hi = std::min(((long long)(t0 + n_streams) << ell) + 2, next);
+            hipLaunchKernelGGL(k_mt_generate, dim3(n_streams), dim3(256), 0, ctx->stream, ctx->mt_ring.p, ctx->mt_end.p, ctx->mt_raw.p,
+                               t0, ell, w_lo, w_hi, last_stream, (block + 1) * MT_N, ctx->mt_need.p, need_words);
+            const long long p_lo = w_first <= pos ? 0 : (w_first - pos + 1) / 2;
+            const long long p_hi = (w_hi - 2 - pos) / 2;
+            hipLaunchKernelGGL((k_pack<GeneratedStream>), dim3((unsigned)pack_blocks), dim3(BLOCK), 0, ctx->stream, D,
+                               GeneratedStream{ctx->mt_raw.p + (pos + 2 * p_lo - w_lo)}, (int64_t)p_lo, (int64_t)(p_hi - p_lo + 1), 1,
+                               ctx->pass_of.p, (int)p);
+        }
+        points_made = true;
+    }
+    for (int t0 = 0; t0 < T && !fused && block_passes.empty(); t0 += per_pass) {
         const int n_streams = std::min(per_pass, T - t0);
         const long long w_lo = (long long)t0 << ell;                                   // origin of the pass's buffer
         const long long w_first = w_lo + (t0 > 0 ? 1 : 0);                             // first word the pass delivers
@@ -1322,7 +1377,7 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
         if (ctx->pack_E > 0 && p_hi >= p_lo && w_hi - 2 - pos >= 0) {
             hipLaunchKernelGGL((k_pack<GeneratedStream>), dim3((unsigned)pack_blocks), dim3(BLOCK), 0, ctx->stream, D,
                                GeneratedStream{ctx->mt_raw.p + (pos + 2 * p_lo - w_lo)}, (int64_t)p_lo, (int64_t)(p_hi - p_lo + 1),
-                               points_only ? 2 : with_points ? 1 : 0);
+                               points_only ? 2 : with_points ? 1 : 0, nullptr, 0);
             if (with_points) points_made = true;
             if (points_only) {
                 raw_only = true;
@@ -1367,6 +1422,7 @@ int rt_trim(RtContext* ctx) {
     if (int rc = materialize_packed(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->mt_raw.release(); ctx->mt_ring.release(); ctx->mt_end.release(); ctx->mt_polys.release(); ctx->mt_need.release(); ctx->mt_stat.release();
+    ctx->mt_ring0.release(); ctx->mt_end0.release(); ctx->pass_of.release();
     ctx->mt_polys_ell = -1;
     ctx->staging.release(); ctx->hit_mask.release(); ctx->hit_pref.release(); ctx->hit_word0.release(); ctx->emit_blocks.release();
     return RT_OK;

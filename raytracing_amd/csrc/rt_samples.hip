@@ -93,8 +93,11 @@ __device__ __forceinline__ SampleColumn sample_column(const Dev& D, int64_t e, i
 // pass): the entry's disk points are made here as well, from the values just read, and k_disk_points
 // need not read the packed uniforms again.  with_points == 2: only the points - the float64 readers
 // (the re-evaluation of uncertified hits) take their uniforms from the raw words, Dev::raw_values_at.
+// pass_of (with_points only, or null): the piece holds whole (node, light) blocks, those with
+// pass_of[node * RT_MAX_LIGHTS + light] == pass; the others are left to the launches of their pieces.
 template <typename Stream>
-__global__ __launch_bounds__(BLOCK, RT_PACK_WAVES) void k_pack(Dev D, Stream chunk, int64_t a, int64_t n, int with_points) {
+__global__ __launch_bounds__(BLOCK, RT_PACK_WAVES) void k_pack(Dev D, Stream chunk, int64_t a, int64_t n, int with_points,
+                                                               const uint8_t* __restrict__ pass_of, int pass) {
     const SceneConst& sc = *D.sc;
     const int64_t b = a + n;
     const int64_t E = D.pack_E;
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(BLOCK, RT_PACK_WAVES) void k_pack(Dev D, Stream chu
             const int N = Lt.n_points;
             double* dst = D.packed + D.pack_base[l] + e;
             if (with_points) {
+                if (c.any && pass_of && pass_of[node * RT_MAX_LIGHTS + l] != pass) continue;
                 // both uniforms of a sample together: packed as below, and the point they select
                 const int NP = (N + 1) >> 1;
                 float4* points = reinterpret_cast<float4*>(D.packed32) + D.pack32_base[l] + (e / TILE) * NP * TILE + (e % TILE);
@@ -351,7 +355,7 @@ struct EmitBlock {
     uint32_t word0;            // first 64-bit word of the node's range in the hit mask
     uint32_t e_first;          // shading-list entry of the node's first shaded hit
     uint32_t light;
-    uint32_t pad;
+    uint32_t node;
 };
 static_assert(sizeof(EmitBlock) == 56, "EmitBlock is read as seven 8-byte words");
 
