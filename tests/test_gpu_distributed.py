@@ -30,9 +30,10 @@ def _watchdog(seconds=240):
     faulthandler.dump_traceback_later(seconds, exit=True)
 
 
-def _worker(rank, world, port, name, w, h, out_path, precision="mixed"):
+def _worker(rank, world, port, name, w, h, out_path, precision="mixed", env=None):
     _watchdog()
     os.environ["RT_MT_POISON"] = "1"    # raw words the generator does not store hold a pattern, not an earlier frame's values
+    os.environ.update(env or {})
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -85,6 +86,24 @@ def test_two_ranks_on_one_gpu(tmp_path, name, precision, tol):
     r = g[name + "_rays"]
     assert int(res["rays"]) == int(r[r >= 3].sum())
     assert int(res["hits"]) == int(g[name + "_hits"].sum())
+
+
+def test_two_ranks_make_the_stream_in_passes(tmp_path):
+    """Row blocks on two ranks with a work buffer far smaller than the whole image's stream: passes of whole
+    (node, light) blocks (8 M words) and passes by ranges (2 M words: the root's block does not fit)."""
+    from raytracing_amd.raytrace import Renderer
+    from raytracing_amd.Scenes.scenes import build_scene
+    w, h = 320, 180
+    np.random.seed(0)
+    with Renderer(build_scene("example_4", w, h)) as r:
+        r.begin_rows(0, h)
+        one = r.render_pixels().reshape(h, w, 3).copy()
+    for words in (1 << 23, 1 << 21):
+        out = str(tmp_path / f"out{words}.npz")
+        mp.spawn(_worker, args=(2, _free_port(), "example_4", w, h, out, "mixed", {"RT_MT_RAW_WORDS": str(words)}), nprocs=2, join=True)
+        res = np.load(out)
+        assert 2 * int(res["total"]) > 4 * words
+        assert np.abs(res["image"] - one).max() <= 2e-5
 
 
 @pytest.mark.parametrize("name", ["example_4", "spot:cubic:16"])
