@@ -135,6 +135,33 @@ def test_trim_gives_the_sample_work_buffers_back():
         assert np.array_equal(r.render_pixels(), first)
 
 
+def test_generator_stores_what_shaded_hits_read(monkeypatch):
+    """RtCounters.generator_words / generator_words_stored: with the store map (default) well under half of
+    the stream's words reach the work buffer in the example scene and in a spotlight scene, all of them
+    with RT_MT_STORE_ALL=1; the frames are the same."""
+    from raytracing_amd.raytrace import Renderer
+    from raytracing_amd.Scenes.scenes import build_scene as by_name
+    for name in ("example_4", "spot:quadratic:16"):
+        frames = {}
+        for store_all in (False, True):
+            if store_all:
+                monkeypatch.setenv("RT_MT_STORE_ALL", "1")
+            else:
+                monkeypatch.delenv("RT_MT_STORE_ALL", raising=False)
+            np.random.seed(21)
+            with Renderer(by_name(name, 480, 270)) as r:
+                r.begin_rows(0, 270)
+                img = r.render_pixels().copy()
+                c = r.ctx.counters()
+            frames[store_all] = img
+            assert c["generator_words"] == 2 * r.samples_total + 624
+            if store_all:
+                assert c["generator_words_stored"] == c["generator_words"]
+            else:
+                assert 0 < c["generator_words_stored"] < 0.5 * c["generator_words"], (name, c)
+        assert np.array_equal(frames[False], frames[True])
+
+
 def test_whole_frame_on_one_gpu_with_a_late_overflow_check():
     """ShardedRenderer.frame(): frames without sampled lights are queued as a whole and the arena's
     overflow flag is looked at with the image; too small an arena is doubled and the frame repeated."""
