@@ -1141,18 +1141,16 @@ int rt_generate_samples(RtContext* ctx, const uint32_t* key, int32_t pos, uint32
             for (int b = 0; b < n_polys; ++b) {
                 if (!mtjump::pow2_words(ell + b, words.data()))
                     return fail(RT_ERR_INVALID, "MT19937 jump tables unavailable (stream too long?)");
-                std::vector<uint16_t> index;
                 for (int r = 0; r < MTJ_ROUNDS; ++r) {
-                    heads[b].first[r] = (int32_t)(lists.size() + index.size() / 2);
+                    heads[b].first[r] = (int32_t)lists.size();
                     for (int i = r * MTJ_CHUNK; i < std::min((r + 1) * MTJ_CHUNK, 19937); ++i)
-                        if ((words[i >> 5] >> (i & 31)) & 1u) index.push_back((uint16_t)mtj_offset(i, r));
-                    while (index.size() % 16) index.push_back((uint16_t)MTJ_PAD);
+                        if ((words[i >> 5] >> (i & 31)) & 1u) lists.push_back(mtj_offset(i, r));
+                    while (lists.size() % 16) lists.push_back(MTJ_PAD);
                 }
-                for (size_t i = 0; i < index.size(); i += 2) lists.push_back((uint32_t)index[i] | ((uint32_t)index[i + 1] << 16));
                 heads[b].first[MTJ_ROUNDS] = (int32_t)lists.size();
             }
             // (one buffer: the heads, then the lists, 16-byte aligned)
-            std::vector<uint32_t> polys(head_words + lists.size() + 8, 0u);
+            std::vector<uint32_t> polys(head_words + lists.size() + 16, 0u);
             memcpy(polys.data(), heads.data(), n_polys * sizeof(JumpPoly));
             memcpy(polys.data() + head_words, lists.data(), lists.size() * 4);
             ctx->mt_polys_ell = -1;

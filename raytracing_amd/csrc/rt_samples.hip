@@ -755,12 +755,12 @@ constexpr int MTJ_ROUNDS = (19937 + MTJ_CHUNK - 1) / MTJ_CHUNK;
 // so that a lane's read needs one addition: coefficient i of round r (i in [r MTJ_CHUNK,
 // (r + 1) MTJ_CHUNK)) is stored as the byte offset of s[i] in the workgroup's array, which keeps s[n]
 // at word (n - r MTJ_CHUNK + 624) & 4095 - so the words the round reads, s[i + j] for j < 624, lie
-// at offset + 4 j without wrapping.  Ascending, two per 32-bit word, padded per round to a multiple
-// of 16 with MTJ_PAD, the offset of 640 words that are kept zero.
+// at offset + 4 j without wrapping.  Ascending, one per 32-bit word (two per word measured the same kernel time: the
+// kernel waits on its LDS reads, not on the scalar unit that unpacks), padded
+// per round to a multiple of 16 with MTJ_PAD, the offset of 640 words that are kept zero.
 // first[r] = first word of round r's list.
 constexpr uint32_t MTJ_PAD = MTJ_RING * 4;
 static_assert(MTJ_CHUNK + 2 * MT_N <= MTJ_RING, "the words a round reads lie in the array without wrapping");
-static_assert(MTJ_PAD <= 0xFFFF, "offsets fit 16 bits");
 struct JumpPoly {
     int32_t first[MTJ_ROUNDS + 1];
 };
@@ -802,15 +802,14 @@ __global__ __launch_bounds__(640) void k_mt_jump(uint32_t* rings, long long* gen
         const JumpPoly& head = heads[level];
         const char* lane_words = reinterpret_cast<const char*>(xs + tid);
         uint32_t acc = 0;
-        for (int w = head.first[r]; w < head.first[r + 1]; w += 8) {
+        for (int w = head.first[r]; w < head.first[r + 1]; w += 16) {
             ConstList src = (ConstList)(uintptr_t)(lists + w);
-            const uint32_t packed[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+            uint32_t offset[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) offset[k] = src[k];
             uint32_t v[16];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                v[2 * k] = *reinterpret_cast<const uint32_t*>(lane_words + (packed[k] & 0xffffu));
-                v[2 * k + 1] = *reinterpret_cast<const uint32_t*>(lane_words + (packed[k] >> 16));
-            }
+            for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const uint32_t*>(lane_words + offset[k]);
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc ^= v[k];
         }
