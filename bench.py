@@ -72,31 +72,31 @@ HBM_PEAK_GBS = 8000.0
 F_ISECT, F_HIT, F_LIGHT, F_SHADOW = 22, 100, 50, 24
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """Time the NumPy float64 oracle on this host: example_1-3 at 800x800 (about 15 s of
-    CPU work; the oracle's throughput does not depend on the image size) as long as
-    the budget allows.  The oracle is a restatement, not the reference: it gathers by sphere
-    index and skips the reference's temporaries, and runs about three times as fast as the
-    reference itself did on the development container (0.56-0.68 Mrays/s on example_1-3);
-    example_4 (30 shadow rays per hit) is left out of the sample."""
+def cpu_baseline(side=240):
+    """Time the NumPy float64 oracle on this host on the headline's own mix: the four example
+    scenes at equal pixel counts (side x side; about 25 s of CPU work, nine tenths of it
+    example_4's 30 shadow rays per hit and light, which the metric does not count as rays).  The
+    oracle is a restatement, not the reference: it gathers by sphere index and skips the
+    reference's temporaries, and runs about three times as fast as the reference itself did on
+    the development container (0.56-0.68 Mrays/s on example_1-3)."""
     from oracle import numpy_oracle
     from raytracing_amd.Scenes.scenes import build_scene
-    rays, spent, used = 0, 0.0, []
-    for name in SCENES[:3]:
-        if spent > seconds_budget:
-            break
-        scene = build_scene(name, 800, 800)
+    rays, spent, per_scene = 0, 0.0, {}
+    for name in SCENES:
+        scene = build_scene(name, side, side)
         t0 = time.perf_counter()
         _, stats = numpy_oracle.render(scene, seed=0)
-        spent += time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        spent += dt
         rays += stats.traced_rays()
-        used.append(name)
+        per_scene[name] = round(stats.traced_rays() / dt / 1e6, 4)
     threads = int(os.environ.get("OPENBLAS_NUM_THREADS", os.environ.get("OMP_NUM_THREADS", "0")) or 0)
     return {"value": rays / spent / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"NumPy float64 oracle, {'+'.join(used)} at 800x800, {rays} rays in {spent:.1f} s "
-                      f"(NumPy elementwise code is single-threaded; BLAS threads setting {threads or 'default'}, "
-                      f"host has {os.cpu_count()} logical CPUs); the oracle is about 3x as fast as the reference's own "
-                      f"code (0.56-0.68 Mrays/s measured on these scenes on another host); example_4 is not in the sample"}
+            "sample": f"NumPy float64 oracle, {'+'.join(SCENES)} at {side}x{side} each (the headline's mix of scenes), "
+                      f"{rays} rays in {spent:.1f} s (NumPy elementwise code is single-threaded; BLAS threads setting "
+                      f"{threads or 'default'}, host has {os.cpu_count()} logical CPUs); the oracle is about 3x as fast as "
+                      f"the reference's own code (0.56-0.68 Mrays/s measured on example_1-3 on another host)",
+            "per_scene": per_scene}
 
 
 def measured_counters(kernel, args, world, field, pattern="pmc_traffic*.json", precision=None):
