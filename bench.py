@@ -72,9 +72,9 @@ HBM_PEAK_GBS = 8000.0
 F_ISECT, F_HIT, F_LIGHT, F_SHADOW = 22, 100, 50, 24
 
 
-def cpu_baseline(side=240):
+def cpu_baseline(side=360):
     """Time the NumPy float64 oracle on this host on the headline's own mix: the four example
-    scenes at equal pixel counts (side x side; about 25 s of CPU work, nine tenths of it
+    scenes at equal pixel counts (side x side; about 20 s of CPU work on the GPU box's host, four fifths of it
     example_4's 30 shadow rays per hit and light, which the metric does not count as rays).  The
     oracle is a restatement, not the reference: it gathers by sphere index and skips the
     reference's temporaries, and runs about three times as fast as the reference itself did on
