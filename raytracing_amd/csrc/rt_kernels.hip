@@ -52,7 +52,7 @@
 #define RT_GRID_CHECK 4     // the candidates of a grid walk take the float64 test every this many steps (a power of two)
 #endif
 #ifndef RT_MIXED_WAVES
-#define RT_MIXED_WAVES 2   // waves per SIMD requested for the mixed-precision surface kernel
+#define RT_MIXED_WAVES 2   // waves per SIMD requested for the mixed-precision surface kernel (4K example_4, with batches of 3 / 5 sample pairs: 1: 4.1 / 4.0 ms, 2: 2.8 / 3.5, 3: 3.3 / 4.3 with 156 / 279 spilled registers, 4: 4.8; batches of 2 at two waves: 2.9)
 #endif
 
 #include "rt_math.h"
