@@ -564,6 +564,7 @@ class FrameJob:
 
     def use_buffer(self, b):
         """Direct the following shading passes to output buffer ``b``."""
+        self.buffer = b
         if self.tiles:
             self.full, self.tile = self.fulls[b], self.tiles[b]
             self.ctx.set_output(self.tile.data_ptr())
@@ -670,8 +671,9 @@ class FrameSet:
     and the lighting of all frames) is then ONE graph that goes by the previous step's sizes
     (rt_set_batch_guess), ONE all-reduce behind it sums the sizes it produced, and if every node
     lies on the same side of SMALL_NUM as guessed, the step is exactly what the level-by-level
-    exchange would have given.  The host learns the outcome when it comes back for the next step
-    (or synchronises); a step whose guess was wrong is then issued again level by level.
+    exchange would have given.  The host learns the outcome one step late - when it comes back for
+    the next step it queues that step first and then looks at the previous one's outcome - or when it
+    synchronises; a step whose guess was wrong is then issued again level by level.
 
     RT_STEP_GRAPH=0 issues the same work without graphs.  With RT_BATCH_EXCHANGE=host the frames
     fall back to per-frame host-side exchanges, issued level by level."""
@@ -713,7 +715,8 @@ class FrameSet:
         self.guess = getattr(self, "guess_buffer", None) if self.speculate else None   # the last step's whole-image batch sizes
         self.guess_valid = False
         self.pending = None                   # (event, output buffer) of a speculative step whose outcome is not known yet
-        self.wrong_host = torch.zeros(1, dtype=torch.bool).pin_memory() if self.speculate else None
+        self.wrong_host = torch.zeros(2, dtype=torch.bool).pin_memory() if self.speculate else None   # per output buffer
+        self.latest_buffer = 0
         self.speculation = {"steps": 0, "redone": 0}
         self.small_num = int(RenderParams(width=width, height=height).small_num)
 
@@ -852,14 +855,18 @@ class FrameSet:
             with torch.cuda.stream(self.stream):
                 self._run("step", None, self._whole)
             return
-        self._settle()
         b = self.steps_issued & 1
         self.steps_issued += 1
+        self.latest_buffer = b
         if self.speculate and self.guess_valid:
             # Geometry of all levels by the last step's sizes and the lighting right behind it, every
             # frame on its own stream as on one GPU; then one sum of the batch sizes and a look at
-            # the outcome, which the host takes only when it comes back for the next step (_settle).
-            # Nothing on the device waits for the collective.
+            # the outcome.  Nothing on the device waits for the collective, and the host takes the
+            # outcome of the step BEFORE this one only now, with this step already queued behind it:
+            # the GPU never waits for the host to come back.  (A step that passes its own look is exact
+            # whatever its guess was - the sizes of a level follow from the decisions of the levels
+            # above it, so sizes that confirm the decisions they were made with are the exact ones - and
+            # this step's guess, copied on the stream, is what the last step really summed.)
             with torch.cuda.stream(self.stream):
                 if self.tiles_sent[b] is not None:
                     self.stream.wait_event(self.tiles_sent[b])
@@ -868,14 +875,16 @@ class FrameSet:
                 shaded.record(self.stream)
                 self.comm.all_reduce_device(self.batches)
                 wrong = ((self.batches < self.small_num) != (self.guess < self.small_num)).any()
-                self.wrong_host.copy_(wrong, non_blocking=True)
+                self.wrong_host[b].copy_(wrong, non_blocking=True)
                 looked = torch.cuda.Event()
                 looked.record(self.stream)
                 self.guess.copy_(self.batches)
-                self.pending = (looked, b)
                 self.speculation["steps"] += 1
             self._send(b, shaded)
+            self._settle()
+            self.pending = (looked, b)
         else:
+            self._settle()
             with torch.cuda.stream(self.stream):
                 self._exact_levels()
             self._finish(b)
@@ -923,11 +932,13 @@ class FrameSet:
         looked, b = self.pending
         self.pending = None
         looked.synchronize()
-        if bool(self.wrong_host.item()):
+        if bool(self.wrong_host[b].item()):
             self.speculation["redone"] += 1
             with self.torch.cuda.stream(self.stream):
                 self._exact_levels()
             self._finish(b)
+            for job in self.jobs:                  # a later step may be queued already: its buffer is the current one
+                job.use_buffer(self.latest_buffer)
 
     def synchronize(self):
         if self.sharded and self.pipelined:
